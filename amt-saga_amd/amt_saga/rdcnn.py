@@ -1,0 +1,303 @@
+"""res_net: the residual deep CNN of /root/reference/RDCNN.py, inference only.
+
+Keeps the reference constructor's argument names (RDCNN.py:42-63) and
+``predict(x)`` (RDCNN.py:591-597); the graph is the one RDCNN.py:176-233
+builds.  The forward pass runs in the HIP library (amt_rdcnn_forward: fp32
+MFMA implicit-GEMM convolutions, fused BN/sigmoid/shortcut epilogues).
+train/test/fit_generator/checkpoint/report/plot are outside the hot path
+ and raise NotImplementedError.
+
+Weights.  The reference ships none; ``init_weights(seed)`` draws synthetic
+ones (Keras initialisers for kernels; BN moving statistics and biases are
+randomised so that they matter).  Canonical order of the blob handed to the C
+ABI (``pack_weights``), per tower t, conv layer i = 1..L in graph order:
+    conv kernel [kh,kw,cin,cout], conv bias, bn gamma, beta, moving mean, var
+    if i is a shortcut layer:
+        if shapes differ: [1x1 kernel [cin_from,cout], bias if channels differ],
+                          shortcut bn gamma, beta, mean, var
+        post-add bn gamma, beta, mean, var
+then dense1 kernel [flat,300], bias, dense2 kernel [300,K], bias.
+Names follow oracle/rdcnn.py ("t0/conv1/kernel", ...); ``load_weights`` reads
+an .npz with those names.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import empty, ptr, require_gpu, stream_ptr, to_dev
+
+
+def _to_list(single):
+    """RDCNN.py:288-302."""
+    if single is None:
+        return []
+    try:
+        len(single)
+        return list(single)
+    except TypeError:
+        return [] if single < 1 else [single]
+
+
+class res_net:
+    def __init__(self,
+                 input_shapes=[(20, 2049, 1,), (20, 256, 1,)],
+                 output_classes=128,
+                 output_range=[0, 128],
+                 batch_size=1,
+                 kernel_sizes=[(3, 32), (3, 8)],
+                 pool_sizes=[(2, 5), (2, 5)],
+                 convolutional_layer_count=15,
+                 feature_expand_frequency=6,
+                 pool_layer_frequency=6,
+                 residual_layer_frequencies=2,
+                 metrics=None,
+                 checkpoint_dir=None, checkpoint_prefix='checkpoint',
+                 checkpoint_frequency=5000,
+                 metrics_prefix='metrics_logs',
+                 weights_load_checkpoint_filename=None,
+                 starting_checkpoint_index=1,
+                 logging_parent=None,
+                 weight_seed=1234):
+        self.batch_size = batch_size          # the HIP forward accepts any B
+        self.out_func_min = 0
+        self.out_func_max = 1
+        self.out_func_factor = 1
+        self.output_classes = int(output_classes)
+        rf = _to_list(residual_layer_frequencies)
+        if len(rf) > 1:
+            raise ValueError('only one residual frequency is supported by the HIP forward')
+        if output_classes > 1:
+            pass
+        elif output_classes == 1:
+            self.out_val_min = output_range[0]
+            self.out_val_max = output_range[1]
+            self.out_val_factor = output_range[1] - output_range[0]
+        else:
+            raise ValueError('Invalid output size {}'.format(str(output_classes)))
+        if not 1 <= len(input_shapes) <= 2:
+            raise ValueError('1 or 2 input towers are supported')
+        self.cfg = dict(
+            input_shapes=[tuple(s) for s in input_shapes],
+            kernel_sizes=[tuple(k) for k in kernel_sizes][:len(input_shapes)],
+            pool_sizes=[tuple(p) for p in pool_sizes][:len(input_shapes)],
+            convolutional_layer_count=int(convolutional_layer_count),
+            feature_expand_frequency=int(feature_expand_frequency or 0),
+            pool_layer_frequency=int(pool_layer_frequency or 0),
+            residual_layer_frequencies=rf,
+            output_classes=int(output_classes),
+            output_range=list(output_range))
+        self.checkpoint_dir = checkpoint_dir
+        self.checkpoint_prefix = checkpoint_prefix
+        self.checkpoint_frequency = checkpoint_frequency
+        self.metrics_prefix = metrics_prefix
+        self.current_batch = starting_checkpoint_index if starting_checkpoint_index is not None else 1
+        self.metrics_train = []
+        self.metrics_test = []
+        self._net = None
+        self._ws = None
+        self.weights = None
+        self.layout = self._walk()
+        if weights_load_checkpoint_filename is not None:
+            self.load_weights(weights_load_checkpoint_filename)
+        else:
+            self.set_weights(self.init_weights(weight_seed))
+
+    # ---- topology (RDCNN.py:176-233) ---------------------------------------------
+    def _walk(self):
+        """[(name, shape)] in canonical blob order + flatten size."""
+        c = self.cfg
+        r = c['residual_layer_frequencies'][0] if c['residual_layer_frequencies'] else 0
+        out = []
+        flat = 0
+        for t, (H, W, C0) in enumerate(c['input_shapes']):
+            if C0 != 1:
+                raise ValueError('input towers must have one channel')
+            kh, kw = c['kernel_sizes'][t]
+            ph, pw = c['pool_sizes'][t]
+            Cc, fo = 1, 32
+            p0 = (H, W, 1)
+            for i in range(1, c['convolutional_layer_count'] + 1):
+                out.append(('t%d/conv%d/kernel' % (t, i), (kh, kw, Cc, fo)))
+                out.append(('t%d/conv%d/bias' % (t, i), (fo,)))
+                for k in ('gamma', 'beta', 'mean', 'var'):
+                    out.append(('t%d/bn%d/%s' % (t, i, k), (fo,)))
+                Cc = fo
+                if r and i % r == 0:
+                    if p0 != (H, W, Cc):
+                        if p0[2] != Cc:
+                            out.append(('t%d/sc%d/kernel' % (t, i), (1, 1, p0[2], Cc)))
+                            out.append(('t%d/sc%d/bias' % (t, i), (Cc,)))
+                        for k in ('gamma', 'beta', 'mean', 'var'):
+                            out.append(('t%d/scbn%d/%s' % (t, i, k), (Cc,)))
+                    for k in ('gamma', 'beta', 'mean', 'var'):
+                        out.append(('t%d/resbn%d/%s' % (t, i, k), (Cc,)))
+                    p0 = (H, W, Cc)
+                if c['pool_layer_frequency'] and i % c['pool_layer_frequency'] == 0:
+                    H, W = H // ph, W // pw
+                if c['feature_expand_frequency'] and i % c['feature_expand_frequency'] == 0:
+                    fo *= 2
+            flat += H * W * Cc
+        out.append(('dense1/kernel', (flat, 300)))
+        out.append(('dense1/bias', (300,)))
+        out.append(('dense2/kernel', (300, c['output_classes'])))
+        out.append(('dense2/bias', (c['output_classes'],)))
+        self.flat = flat
+        return out
+
+    def init_weights(self, seed=1234):
+        """Synthetic weights: glorot-uniform kernels (Keras default), small random
+        biases, BN gamma~U(2.5,4.5) (large on purpose: with unit gamma a 33-layer
+        sigmoid stack forgets its input and parity tests would see nothing),
+        beta~N(0,0.2), mean~N(0,0.2), var~U(0.5,1.5)."""
+        rng = np.random.default_rng(seed)
+        w = {}
+        for name, shape in self.layout:
+            kind = name.rsplit('/', 1)[1]
+            if kind == 'kernel':
+                if len(shape) == 4:
+                    fan_in = shape[0] * shape[1] * shape[2]
+                    fan_out = shape[0] * shape[1] * shape[3]
+                else:
+                    fan_in, fan_out = shape
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                a = rng.uniform(-lim, lim, shape)
+            elif kind == 'bias':
+                a = rng.normal(0, 0.05, shape)
+            elif kind == 'gamma':
+                a = rng.uniform(2.5, 4.5, shape)
+            elif kind in ('beta', 'mean'):
+                a = rng.normal(0, 0.2, shape)
+            else:
+                a = rng.uniform(0.5, 1.5, shape)
+            w[name] = a.astype(np.float32)
+        return w
+
+    def pack_weights(self, w):
+        parts = []
+        for name, shape in self.layout:
+            a = np.asarray(w[name], dtype=np.float32)
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError('Invalid Input shape. Expected: {} . Got: {} ({})'.format(
+                    shape, a.shape, name))
+            parts.append(a.reshape(-1))
+        return np.ascontiguousarray(np.concatenate(parts))
+
+    def _desc(self):
+        c = self.cfg
+        d = _lib.RdcnnDesc()
+        d.n_towers = len(c['input_shapes'])
+        for t in range(d.n_towers):
+            d.in_h[t], d.in_w[t] = c['input_shapes'][t][0], c['input_shapes'][t][1]
+            d.kh[t], d.kw[t] = c['kernel_sizes'][t]
+            d.pool_h[t], d.pool_w[t] = c['pool_sizes'][t]
+        d.conv_layers = c['convolutional_layer_count']
+        d.feature_expand_frequency = c['feature_expand_frequency']
+        d.pool_layer_frequency = c['pool_layer_frequency']
+        d.residual_frequency = c['residual_layer_frequencies'][0] if c['residual_layer_frequencies'] else 0
+        d.dense_units = 300
+        d.output_classes = c['output_classes']
+        if c['output_classes'] == 1:
+            d.out_lo, d.out_hi = float(c['output_range'][0]), float(c['output_range'][1])
+        else:
+            d.out_lo, d.out_hi = 0.0, 1.0
+        return d
+
+    def set_weights(self, w):
+        """Upload a weight dict (see module docstring) to the device."""
+        self.weights = w
+        self._blob = self.pack_weights(w)
+        self._release()
+
+    def _ensure(self):
+        if self._net is not None:
+            return
+        lib = _lib.load()
+        require_gpu()
+        d = self._desc()
+        n = lib.amt_rdcnn_param_count(C.byref(d))
+        if n != self._blob.size:
+            raise ValueError('Invalid Input shape. Expected: {} . Got: {}'.format(n, self._blob.size))
+        h = C.c_void_p()
+        _lib.check(lib.amt_rdcnn_create(C.byref(h), C.byref(d),
+                                        self._blob.ctypes.data_as(C.c_void_p), self._blob.size))
+        self._net = h
+        self._lib = lib
+
+    def _release(self):
+        if getattr(self, '_net', None) is not None:
+            self._lib.amt_rdcnn_destroy(self._net)
+        self._net = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def load_weights(self, filename):                       # RDCNN.py:778-782
+        with np.load(filename) as z:
+            self.set_weights({k: z[k] for k in z.files})
+
+    def save_weights(self, filename):
+        np.savez(filename, **self.weights)
+
+    @property
+    def flops_per_window(self):
+        self._ensure()
+        return float(self._lib.amt_rdcnn_flops_per_window(self._net))
+
+    # ---- forward ---------------------------------------------------------------
+    def predict_device(self, xs, return_logits=False):
+        """xs: list (one per tower) of device tensors [B, H, W] f32 (NHWC, C=1).
+        Returns a device tensor [B, K] (and the logits if asked)."""
+        self._ensure()
+        B = xs[0].shape[0]
+        for t, x in enumerate(xs):
+            H, W, _ = self.cfg['input_shapes'][t]
+            if tuple(x.shape[1:3]) != (H, W) or x.shape[0] != B:
+                raise ValueError('Invalid Input shape. Expected: {} . Got: {}'.format(
+                    (H, W), tuple(x.shape[1:3])))
+        need = self._lib.amt_rdcnn_workspace_bytes(self._net, B)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = empty(((need + 3) // 4,))
+        K = self.cfg['output_classes']
+        y = empty((B, K))
+        lg = empty((B, K)) if return_logits else None
+        arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        _lib.check(self._lib.amt_rdcnn_forward(self._net, arr, B, ptr(y), ptr(lg), ptr(self._ws),
+                                               self._ws.numel() * 4, stream_ptr()))
+        return (y, lg) if return_logits else y
+
+    def predict(self, x):
+        """RDCNN.py:591-597: x is (B,H,W,1) (or a list of such, one per tower);
+        returns the scaled regression value (B,1) or softmax probabilities (B,K)."""
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        dx = []
+        for a in xs:
+            a = a if isinstance(a, torch.Tensor) else np.asarray(a)
+            if a.ndim == 4:
+                a = a[..., 0]
+            dx.append(to_dev(a))
+        return self.predict_device(dx).cpu().numpy()
+
+    def _scale_output_to_activation(self, x):               # RDCNN.py:304-306
+        return ((x - self.out_val_min) / self.out_val_factor) * self.out_func_factor + self.out_func_min
+
+    def _scale_activation_to_output(self, x):               # RDCNN.py:308-310
+        return ((x - self.out_func_min) / self.out_func_factor) * self.out_val_factor + self.out_val_min
+
+    # ---- training-side API: outside the hot path ---------------------------------
+    def train(self, x, y):
+        raise NotImplementedError('training is outside the hot path (SURVEY 8f row 4)')
+
+    def test(self, x, y, use_predict=False):
+        raise NotImplementedError('training/test bookkeeping is outside the hot path')
+
+    def fit_generator(self, *a, **k):
+        raise NotImplementedError('training is outside the hot path')
+
+    def save_checkpoint(self):
+        raise NotImplementedError('checkpointing is outside the hot path')

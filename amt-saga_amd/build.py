@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Build libamt_saga_hip.so (gfx950) in-tree with hipcc.
+
+    python amt-saga_amd/build.py [--force]
+
+The shared library lands in amt-saga_amd/lib/ (git-ignored, travels with
+gpurun snapshots).  No torch headers are involved: the C ABI (include/amt_saga.h)
+takes plain device pointers.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libamt_saga_hip.so')
+SOURCES = ['amt_stft.hip', 'amt_subtract.hip', 'amt_features.hip', 'amt_cqt.hip',
+           'amt_rdcnn.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math',
+         '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+        [os.path.join(ROOT, 'include', 'amt_saga.h')]
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s) + '.o')
+        objs.append(o)
+        if force or any(_newer(d, o) for d in [s] + deps[len(srcs):]):
+            cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on ' + s)
+    if force or procs or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

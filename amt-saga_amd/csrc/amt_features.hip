@@ -1,0 +1,122 @@
+// Feature gathers that turn the residual spectrogram into the RDCNN head inputs.
+//
+// Replaces, for a batch of windows at once:
+//   audio_complete.compress_bands (util_audio.py:436-466) + _resize (:384-409)
+//       -> C_timing of training.py:333-336
+//   audio_complete.resize(..., ['mag','ph']) (:469-507) + section_power (:334-349)
+//       + the scalings of training.py:347-363 -> F_sw_inst_foc* / ph features
+// All HBM-bound gathers over frame-major spectra; outputs are laid out
+// [B][bands][frames] = the NHWC (C = 1) tensors the heads consume.
+#include "amt_common.h"
+
+// One wave per (window, output frame): the row is read coalesced (lane + 64*q),
+// every band is a masked wave reduction.  F <= 64*MAXQ.
+template <int MAXQ>
+__global__ __launch_bounds__(256) void compress_bands_kernel(
+    const float *__restrict__ mag, int T, int F, int ldf, size_t spec_stride,
+    const int32_t *__restrict__ edges, int bands, const float *__restrict__ ref,
+    const int32_t *__restrict__ src_frame, float *__restrict__ out, int target) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // output frame
+    const int b = blockIdx.y;
+    if (j >= target) return;                                // whole wave exits together
+    const int t = src_frame ? src_frame[j] : j;
+    float v[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int f = lane + 64 * q;
+        v[q] = (t >= 0 && t < T && f < F) ? mag[(size_t)b * spec_stride + (size_t)t * ldf + f] : 0.f;
+    }
+    const float r = ref ? ref[b] : 1.0f;
+    float *o = out + ((size_t)b * bands) * target + j;
+    for (int i = 0; i < bands; ++i) {
+        const int lo = edges[i], hi = edges[i + 1];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int f = lane + 64 * q;
+            s += (f >= lo && f < hi) ? v[q] : 0.f;
+        }
+        s = wave_sum(s);
+        if (lane == 0) o[(size_t)i * target] = __fdiv_rn(__fdiv_rn(s, (float)(hi - lo)), r);
+    }
+}
+
+// One workgroup per window: gather [bands][frames] from `frames` source rows.
+__global__ __launch_bounds__(256) void short_window_kernel(
+    const float *__restrict__ mag, const float2 *__restrict__ phase, int T, int F, int ldf,
+    size_t spec_stride, const int32_t *__restrict__ src_frame, int frames,
+    const int32_t *__restrict__ band_min, int bands, const float *__restrict__ ref, int mode,
+    float *__restrict__ out) {
+    __shared__ float red[16];
+    __shared__ float bmax;
+    const int b = blockIdx.x;
+    const int n = bands * frames;
+    const int lo = band_min ? band_min[b] : 0;
+    const float *mg = mag + (size_t)b * spec_stride;
+    const float2 *ph = phase ? phase + (size_t)b * spec_stride : nullptr;
+    float *o = out + (size_t)b * n;
+    float lmax = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / frames, j = i - r * frames;
+        const int t = src_frame[b * frames + j];
+        const int f = lo + r;
+        const bool ok = t >= 0 && t < T && f >= 0 && f < F;
+        float val;
+        if (mode == 2) {
+            const float2 q = ok ? ph[(size_t)t * ldf + f] : make_float2(0.f, 0.f);
+            val = __fdiv_rn(atan2f(q.y, q.x) + 3.15f, 6.3f);
+        } else {
+            const float m = ok ? mg[(size_t)t * ldf + f] : 0.f;
+            if (mode == 0) val = ref ? __fdiv_rn(m, ref[b]) : m;
+            else { val = log10f(__fmul_rn(m, 1000.0f) + 1.0f); lmax = fmaxf(lmax, val); }
+        }
+        o[i] = val;
+    }
+    if (mode == 1) {
+        lmax = block_max(lmax, red);
+        if (threadIdx.x == 0) bmax = lmax;
+        __syncthreads();
+        const float d = bmax;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = __fdiv_rn(o[i], d);
+    }
+}
+
+extern "C" {
+
+int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
+                       const int32_t *edges, int bands, const float *ref,
+                       const int32_t *src_frame, float *out, int target_frames, void *stream) {
+    if (!mag || !edges || !out || B <= 0 || T <= 0 || bands <= 0 || target_frames <= 0)
+        return AMT_E_INVALID;
+    if (F <= 0 || ldf < F) return AMT_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((target_frames + 3) / 4, B);
+    if (F <= 64 * 5)
+        compress_bands_kernel<5><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+    else if (F <= 64 * 17)
+        compress_bands_kernel<17><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+    else if (F <= 64 * 33)
+        compress_bands_kernel<33><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+    else
+        return AMT_E_UNSUPPORTED;
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_short_window(const float *mag, const float *phase_ri, int B, int T, int F, int ldf,
+                     size_t spec_stride, const int32_t *src_frame, int frames,
+                     const int32_t *band_min, int bands, const float *ref, int mode, float *out,
+                     void *stream) {
+    if (!out || !src_frame || B <= 0 || T <= 0 || frames <= 0 || bands <= 0) return AMT_E_INVALID;
+    if (mode < 0 || mode > 2) return AMT_E_INVALID;
+    if ((mode == 2 && !phase_ri) || (mode != 2 && !mag)) return AMT_E_ATTRIB;
+    if (F <= 0 || ldf < F) return AMT_E_SHAPE;
+    short_window_kernel<<<B, 256, 0, (hipStream_t)stream>>>(
+        mag, reinterpret_cast<const float2 *>(phase_ri), T, F, ldf, spec_stride, src_frame, frames,
+        band_min, bands, ref, mode, out);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+}  // extern "C"

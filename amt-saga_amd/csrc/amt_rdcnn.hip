@@ -1,0 +1,775 @@
+// RDCNN forward (res_net.predict) for gfx950: fp32-exact MFMA implicit-GEMM
+// convolutions with fused BN + sigmoid (+ shortcut add + BN) epilogues.
+//
+// Replaces keras Model.predict for the graph built in
+// /root/reference/RDCNN.py:176-233 (+ _add_shortcut :312-335, output scaling
+// :304-310, :591-597) -- see oracle/rdcnn.py for the CPU restatement.
+//
+// Data layout in HBM: activations NHWC f32, [B][H][W][C]; the flatten order of
+// Keras (H, W, C) is then the memory order, so Dense consumes it as is.
+//
+// Conv kernel (Cin multiple of 32): one 256-thread workgroup computes
+// 128*MT output positions x Cout channels.  GEMM view: M = positions,
+// N = Cout, K = (dy, dx, cin).  v_mfma_f32_32x32x2_f32 (f32 in, f32 acc: a
+// k-ordered fmaf chain, bitwise) -- the contraction the north star puts on
+// MFMA while keeping float parity with the CPU.
+//   * the input tile incl. the conv halo (explicit zeros = Keras "same"
+//     padding, asymmetric for even kernels) is staged once per 32-channel
+//     chunk into LDS as [pos][33] (pad 1 float: A-fragment reads hit 32
+//     distinct banks);
+//   * weights are pre-arranged on the host as [cchunk][tap][c][j][nt] so a
+//     (tap, chunk) slab is one linear copy into a double-buffered LDS slab
+//     and a lane's B fragments for all N-tiles are one ds_read_b32/b64/b128;
+//   * one barrier per tap; 16 k-steps x MT x NT MFMAs between barriers;
+//   * epilogue: acc*s1+t1 -> sigmoid -> (+shortcut)*s2+t2 -> coalesced NHWC
+//     stores (a store instruction = two full 128-B channel rows).
+#include "amt_common.h"
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RD_CC 32           // channels per staged chunk
+#define RD_CSTRIDE 33      // LDS floats per staged position
+#define RD_BN_EPS 1e-3f
+
+struct ConvParams {
+    const float *in;  size_t in_win_stride;      // [B][H][W][CIN]
+    float *out;       size_t out_win_stride;     // [B][H][W][COUT]
+    const float *sc;  size_t sc_win_stride;      // shortcut tensor (same shape as out) or null
+    const float *w;                              // pre-arranged weights
+    const float *s1, *t1, *s2, *t2;              // folded BN (s2/t2 null if no residual)
+    int B, H, W;
+    int TH, TW, NWIN;                            // workgroup tile
+    int tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int KH, int KW, int CIN, int COUT, int MT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+    constexpr int NT = COUT / 32;
+    constexpr int NCHUNK = CIN / RD_CC;
+    constexpr int NTAPS = KH * KW;
+    constexpr int PCAP = 128 * MT;               // positions per workgroup
+    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
+    constexpr int WSLAB = RD_CC * COUT;           // floats per (tap, chunk) weight slab
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wbuf = smem;                           // [2][WSLAB]
+    int *pos_sp = reinterpret_cast<int *>(smem + 2 * WSLAB);   // [PCAP] spatial index or -1
+    int *pos_win = pos_sp + PCAP;                 // [PCAP] global window
+    float *in_lds = reinterpret_cast<float *>(pos_win + PCAP); // [POSIN][33]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int THin = p.TH + KH - 1, TWin = p.TW + KW - 1;
+    // block -> (window group, tile row, tile col)
+    int bid = blockIdx.x;
+    const int tc = bid % p.tiles_w; bid /= p.tiles_w;
+    const int tr = bid % p.tiles_h; bid /= p.tiles_h;
+    const int win0 = bid * p.NWIN;
+    const int r0 = tr * p.TH, c0 = tc * p.TW;
+    const int ptile = p.TH * p.TW;
+
+    for (int q = tid; q < PCAP; q += 256) {
+        const int w_ = q / ptile, rem = q - w_ * ptile;
+        const int r = rem / p.TW, c = rem - r * p.TW;
+        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
+        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
+        pos_win[q] = win0 + w_;
+    }
+    // per-lane LDS base (floats) of the A fragment for each of this wave's M-tiles
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int q = (wid * MT + mt) * 32 + (lane & 31);
+        int w_ = q / ptile, rem = q - w_ * ptile;
+        int r = rem / p.TW, c = rem - r * p.TW;
+        if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }       // padding rows of the tile: any valid address
+        abase[mt] = ((w_ * THin + r) * TWin + c) * RD_CSTRIDE + (lane >> 5);
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    constexpr int WV4 = WSLAB / 4 / 256;          // float4 per thread per slab (1, 2 or 4)
+    static_assert(WSLAB % (4 * 256) == 0, "slab split");
+    const float4 *wg4 = reinterpret_cast<const float4 *>(p.w);
+
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        __syncthreads();                          // previous chunk fully consumed
+        // ---- stage the input tile (32 channels) with its zero halo -------------
+        {
+            const int c4 = tid & 7;               // float4 within the 32 channels
+            const int cl = tid >> 3;              // column lane 0..31
+            for (int wr = 0; wr < p.NWIN * THin; ++wr) {
+                const int w_ = wr / THin, ri = wr - w_ * THin;
+                const int gr = r0 - PAD_T + ri;
+                const int gw = win0 + w_;
+                const bool rok = gr >= 0 && gr < p.H && gw < p.B;
+                const float *src = p.in + (size_t)gw * p.in_win_stride +
+                                   ((size_t)gr * p.W) * CIN + ch * RD_CC + c4 * 4;
+                float *dst = in_lds + (size_t)wr * TWin * RD_CSTRIDE + c4 * 4;
+                for (int ci = cl; ci < TWin; ci += 32) {
+                    const int gc = c0 - PAD_L + ci;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rok && gc >= 0 && gc < p.W)
+                        v = *reinterpret_cast<const float4 *>(src + (size_t)gc * CIN);
+                    float *d = dst + ci * RD_CSTRIDE;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+        }
+        // ---- first weight slab of this chunk ---------------------------------
+        {
+            const float4 *src = wg4 + (size_t)(ch * NTAPS) * (WSLAB / 4);
+            float4 *dst = reinterpret_cast<float4 *>(wbuf);
+#pragma unroll
+            for (int i = 0; i < WV4; ++i) dst[tid + i * 256] = src[tid + i * 256];
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int dy = 0; dy < KH; ++dy) {
+            for (int dx = 0; dx < KW; ++dx) {
+                const int tap = dy * KW + dx;
+                float4 wpre[WV4];
+                const bool more = tap + 1 < NTAPS;
+                if (more) {
+                    const float4 *src = wg4 + (size_t)(ch * NTAPS + tap + 1) * (WSLAB / 4);
+#pragma unroll
+                    for (int i = 0; i < WV4; ++i) wpre[i] = src[tid + i * 256];
+                }
+                const int tapoff = (dy * TWin + dx) * RD_CSTRIDE;
+                const float *wb = wbuf + cur * WSLAB + ((lane >> 5) * 32 + (lane & 31)) * NT;
+#pragma unroll
+                for (int cp = 0; cp < RD_CC / 2; ++cp) {
+                    float a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = in_lds[abase[mt] + tapoff + 2 * cp];
+                    float bfr[NT];
+                    const float *wrow = wb + (2 * cp) * 32 * NT;
+                    if constexpr (NT == 1) {
+                        bfr[0] = wrow[0];
+                    } else if constexpr (NT == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2 *>(wrow);
+                        bfr[0] = t2.x; bfr[1] = t2.y;
+                    } else {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(wrow);
+                        bfr[0] = t4.x; bfr[1] = t4.y; bfr[2] = t4.z; bfr[3] = t4.w;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                }
+                if (more) {
+                    float4 *dst = reinterpret_cast<float4 *>(wbuf + (cur ^ 1) * WSLAB);
+#pragma unroll
+                    for (int i = 0; i < WV4; ++i) dst[tid + i * 256] = wpre[i];
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+    // ---- epilogue ---------------------------------------------------------------
+    const int j = lane & 31;
+    float s1[NT], t1[NT], s2[NT], t2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = p.s1[nt * 32 + j]; t1[nt] = p.t1[nt * 32 + j];
+        s2[nt] = p.s2 ? p.s2[nt * 32 + j] : 1.f;
+        t2[nt] = p.t2 ? p.t2[nt * 32 + j] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int q = (wid * MT + mt) * 32 + row;
+            const int sp = pos_sp[q];
+            if (sp < 0) continue;
+            const int gw = pos_win[q];
+            float *o = p.out + (size_t)gw * p.out_win_stride + (size_t)sp * COUT + j;
+            const float *scp = p.sc ? p.sc + (size_t)gw * p.sc_win_stride + (size_t)sp * COUT + j : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = sigmoidf_(acc[mt][nt][e] * s1[nt] + t1[nt]);
+                if (scp) v = (v + scp[nt * 32]) * s2[nt] + t2[nt];
+                o[nt * 32] = v;
+            }
+        }
+    }
+}
+
+// ---- first layer (Cin = 1): direct convolution on the VALU ---------------------
+// thread = (position, cout); consecutive threads -> consecutive cout (coalesced
+// NHWC stores, conflict-free weight reads, input broadcast).
+struct Conv1Params {
+    const float *in; size_t in_win_stride;       // [B][H][W]
+    float *out; size_t out_win_stride;
+    const float *sc; size_t sc_win_stride;
+    const float *w;                              // [KH*KW][COUT]
+    const float *s1, *t1, *s2, *t2;
+    int B, H, W, KH, KW, COUT;
+};
+__global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wl = smem;                            // [KH*KW][COUT]
+    const int ntap = p.KH * p.KW;
+    for (int i = threadIdx.x; i < ntap * p.COUT; i += 256) wl[i] = p.w[i];
+    __syncthreads();
+    const int pad_t = (p.KH - 1) / 2, pad_l = (p.KW - 1) / 2;
+    const int co = threadIdx.x % p.COUT;
+    const int ppb = 256 / p.COUT;                // positions per block pass
+    const size_t hw = (size_t)p.H * p.W;
+    const size_t total = (size_t)p.B * hw;
+    const float s1 = p.s1[co], t1 = p.t1[co];
+    const float s2 = p.s2 ? p.s2[co] : 1.f, t2 = p.t2 ? p.t2[co] : 0.f;
+    for (size_t pos = (size_t)blockIdx.x * ppb + threadIdx.x / p.COUT; pos < total;
+         pos += (size_t)gridDim.x * ppb) {
+        const int b = (int)(pos / hw);
+        const int sp = (int)(pos - (size_t)b * hw);
+        const int r = sp / p.W, c = sp - r * p.W;
+        const float *x = p.in + (size_t)b * p.in_win_stride;
+        float acc = 0.f;
+        for (int dy = 0; dy < p.KH; ++dy) {
+            const int gr = r + dy - pad_t;
+            if (gr < 0 || gr >= p.H) continue;
+            for (int dx = 0; dx < p.KW; ++dx) {
+                const int gc = c + dx - pad_l;
+                if (gc < 0 || gc >= p.W) continue;
+                acc = fmaf(x[(size_t)gr * p.W + gc], wl[(dy * p.KW + dx) * p.COUT + co], acc);
+            }
+        }
+        float v = sigmoidf_(acc * s1 + t1);
+        if (p.sc) v = (v + p.sc[(size_t)b * p.sc_win_stride + (size_t)sp * p.COUT + co]) * s2 + t2;
+        p.out[(size_t)b * p.out_win_stride + (size_t)sp * p.COUT + co] = v;
+    }
+}
+
+// ---- shortcut projection: BN(avgpool(conv1x1(x)))  (RDCNN.py:328-334) -----------
+struct ProjParams {
+    const float *in; size_t in_win_stride;       // [B][H][W][CIN]
+    float *out; size_t out_win_stride;           // [B][HO][WO][COUT]
+    const float *w;                              // [CIN][COUT] or null (identity channels)
+    const float *s, *t;                          // folded: out = s*(sum) + t  (bias inside t)
+    int B, H, W, CIN, COUT, PH, PW, HO, WO;
+};
+__global__ __launch_bounds__(256) void proj_kernel(ProjParams p) {
+    const size_t total = (size_t)p.B * p.HO * p.WO * p.COUT;
+    const float inv = 1.0f / (float)(p.PH * p.PW);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % p.COUT);
+        size_t r = i / p.COUT;
+        const int wo = (int)(r % p.WO); r /= p.WO;
+        const int ho = (int)(r % p.HO);
+        const int b = (int)(r / p.HO);
+        const float *x = p.in + (size_t)b * p.in_win_stride;
+        float acc = 0.f;
+        if (p.w) {
+            for (int ci = 0; ci < p.CIN; ++ci) {
+                float a = 0.f;
+                for (int dy = 0; dy < p.PH; ++dy)
+                    for (int dx = 0; dx < p.PW; ++dx)
+                        a += x[((size_t)(ho * p.PH + dy) * p.W + (wo * p.PW + dx)) * p.CIN + ci];
+                acc = fmaf(a * inv, p.w[ci * p.COUT + co], acc);
+            }
+        } else {
+            for (int dy = 0; dy < p.PH; ++dy)
+                for (int dx = 0; dx < p.PW; ++dx)
+                    acc += x[((size_t)(ho * p.PH + dy) * p.W + (wo * p.PW + dx)) * p.CIN + co];
+            acc *= inv;
+        }
+        p.out[(size_t)b * p.out_win_stride + ((size_t)ho * p.WO + wo) * p.COUT + co] =
+            acc * p.s[co] + p.t[co];
+    }
+}
+
+// ---- MaxPooling2D (valid, stride = pool) ------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ in,
+                                                       size_t in_win_stride, float *__restrict__ out,
+                                                       size_t out_win_stride, int B, int H, int W,
+                                                       int C, int PH, int PW, int HO, int WO) {
+    const size_t total = (size_t)B * HO * WO * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int wo = (int)(r % WO); r /= WO;
+        const int ho = (int)(r % HO);
+        const int b = (int)(r / HO);
+        const float *x = in + (size_t)b * in_win_stride;
+        float m = -INFINITY;
+        for (int dy = 0; dy < PH; ++dy)
+            for (int dx = 0; dx < PW; ++dx)
+                m = fmaxf(m, x[((size_t)(ho * PH + dy) * W + (wo * PW + dx)) * C + c]);
+        out[(size_t)b * out_win_stride + ((size_t)ho * WO + wo) * C + c] = m;
+    }
+}
+
+// ---- Dense: y[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); 8 windows per block --
+#define DN_MB 8
+#define DN_KC 256
+__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ x, int K,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ bias, int N,
+                                                     float *__restrict__ y, int B, int act) {
+    __shared__ float xs[DN_MB][DN_KC];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = blockIdx.y * DN_MB;
+    float acc[DN_MB];
+#pragma unroll
+    for (int m = 0; m < DN_MB; ++m) acc[m] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += DN_KC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < DN_MB * DN_KC; i += 256) {
+            const int m = i / DN_KC, kk = i - m * DN_KC;
+            xs[m][kk] = (b0 + m < B && k0 + kk < K) ? x[(size_t)(b0 + m) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        if (n < N) {
+            const int kend = min(DN_KC, K - k0);
+            for (int kk = 0; kk < kend; ++kk) {
+                const float wv = w[(size_t)(k0 + kk) * N + n];
+#pragma unroll
+                for (int m = 0; m < DN_MB; ++m) acc[m] = fmaf(xs[m][kk], wv, acc[m]);
+            }
+        }
+    }
+    if (n < N) {
+        const float bv = bias[n];
+#pragma unroll
+        for (int m = 0; m < DN_MB; ++m) {
+            if (b0 + m < B) {
+                float v = acc[m] + bv;
+                if (act == 1) v = sigmoidf_(v);
+                y[(size_t)(b0 + m) * N + n] = v;
+            }
+        }
+    }
+}
+
+// ---- output activation: softmax (K > 1) or sigmoid + range scaling (K == 1) -------
+__global__ void head_output_kernel(const float *__restrict__ logits, float *__restrict__ y, int B,
+                                   int K, float lo, float hi) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *l = logits + (size_t)b * K;
+    float *o = y + (size_t)b * K;
+    if (K == 1) {
+        const float a = 1.0f / (1.0f + expf(-l[0]));
+        o[0] = a * (hi - lo) + lo;                 // RDCNN.py:308-310 with out_func range [0,1]
+    } else {
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, l[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(l[k] - m);
+        for (int k = 0; k < K; ++k) o[k] = expf(l[k] - m) / s;
+    }
+}
+
+// =====================================================================================
+// Host side: topology walk, weight folding / pre-arrangement, launch plan
+// =====================================================================================
+struct DevBuf { float *p = nullptr; };
+
+struct ConvOp {
+    int cin, cout, H, W, kh, kw;
+    float *w = nullptr, *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
+    bool residual = false;
+    int sc_proj = -1;          // index into projs, -1 => identity shortcut
+    int pool_after = 0;        // 1 => maxpool (ph, pw) follows
+    int TH = 0, TW = 0, NWIN = 1, MT = 2;
+    size_t lds = 0;
+};
+struct ProjOp {
+    int cin, cout, H, W, ph, pw, HO, WO;
+    float *w = nullptr, *s = nullptr, *t = nullptr;
+};
+struct Tower {
+    int in_h, in_w, ph, pw;
+    std::vector<ConvOp> convs;
+    std::vector<ProjOp> projs;
+    size_t max_act = 0;        // floats per window of the largest activation
+    int out_h, out_w, out_c;
+};
+struct amt_rdcnn {
+    amt_rdcnn_desc d;
+    std::vector<Tower> towers;
+    std::vector<float *> allocs;
+    float *d1w = nullptr, *d1b = nullptr, *d2w = nullptr, *d2b = nullptr;
+    int flat = 0;
+    double flops = 0;
+};
+
+static int upload(amt_rdcnn *n, const std::vector<float> &h, float **out) {
+    float *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(float)) != hipSuccess) return AMT_E_NOMEM;
+    n->allocs.push_back(d);
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return AMT_E_HIP;
+    *out = d;
+    return AMT_OK;
+}
+
+struct BN { const float *g, *b, *m, *v; };
+static void fold_bn(const BN &bn, int c, const float *bias, std::vector<float> &s, std::vector<float> &t) {
+    s.resize(c); t.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float sc = bn.g[i] / sqrtf(bn.v[i] + RD_BN_EPS);
+        s[i] = sc;
+        t[i] = bn.b[i] + ((bias ? bias[i] : 0.f) - bn.m[i]) * sc;
+    }
+}
+
+static void choose_tile(ConvOp &c) {
+    double best = -1;
+    for (int MT = 2; MT >= 1; --MT) {
+        const int pcap = 128 * MT;
+        auto consider = [&](int TH, int TW, int NWIN) {
+            const size_t posin = (size_t)NWIN * (TH + c.kh - 1) * (TW + c.kw - 1);
+            const size_t lds = posin * RD_CSTRIDE * 4 + 2 * (size_t)RD_CC * c.cout * 4 + (size_t)pcap * 8;
+            if (lds > 150 * 1024) return;
+            const double tiles = (double)((c.H + TH - 1) / TH) * ((c.W + TW - 1) / TW) / NWIN;
+            double eff = (double)c.H * c.W / (tiles * pcap);
+            if (lds > 78 * 1024) eff *= 0.93;          // prefer two workgroups per CU
+            if (eff > best + 1e-9) { best = eff; c.TH = TH; c.TW = TW; c.NWIN = NWIN; c.MT = MT; c.lds = lds; }
+        };
+        if (c.H * c.W <= pcap) {
+            for (int nw = pcap / (c.H * c.W); nw >= 1; --nw) consider(c.H, c.W, nw);
+        }
+        for (int TH = 1; TH <= c.H && TH <= pcap; ++TH) {
+            int TW = pcap / TH;
+            if (TW > c.W) TW = c.W;
+            if (TW >= 1) consider(TH, TW, 1);
+            // also the narrowest TW that keeps the same number of column tiles
+            const int nct = (c.W + TW - 1) / TW;
+            const int TW2 = (c.W + nct - 1) / nct;
+            if (TW2 >= 1 && TW2 <= TW) consider(TH, TW2, 1);
+        }
+    }
+}
+
+template <int KH, int KW, int CIN, int COUT, int MT>
+static int launch_conv_t(const ConvOp &c, const ConvParams &p, hipStream_t st) {
+    auto kern = conv_mfma_kernel<KH, KW, CIN, COUT, MT>;
+    static size_t attr_set = 0;
+    if (c.lds > attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(152 * 1024)));
+        attr_set = 152 * 1024;
+    }
+    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
+    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
+    kern<<<grid, 256, c.lds, st>>>(p);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+template <int KH, int KW>
+static int launch_conv_k(const ConvOp &c, const ConvParams &p, hipStream_t st) {
+#define RD_CASE(CI, CO)                                                         \
+    if (c.cin == CI && c.cout == CO)                                            \
+        return c.MT == 2 ? launch_conv_t<KH, KW, CI, CO, 2>(c, p, st)           \
+                         : launch_conv_t<KH, KW, CI, CO, 1>(c, p, st);
+    RD_CASE(32, 32) RD_CASE(32, 64) RD_CASE(64, 64) RD_CASE(64, 128) RD_CASE(128, 128)
+#undef RD_CASE
+    return AMT_E_UNSUPPORTED;
+}
+
+static int launch_conv(const ConvOp &c, const ConvParams &p, hipStream_t st) {
+    if (c.kh == 4 && c.kw == 16) return launch_conv_k<4, 16>(c, p, st);
+    if (c.kh == 4 && c.kw == 2) return launch_conv_k<4, 2>(c, p, st);
+    if (c.kh == 2 && c.kw == 2) return launch_conv_k<2, 2>(c, p, st);
+    return AMT_E_UNSUPPORTED;
+}
+
+static bool conv_supported(int kh, int kw) {
+    return (kh == 4 && kw == 16) || (kh == 4 && kw == 2) || (kh == 2 && kw == 2);
+}
+
+// number of f32 the canonical blob must hold; also validates the topology
+static long walk_count(const amt_rdcnn_desc &d, int *flat_out, std::string *err) {
+    long n = 0;
+    int flat = 0;
+    for (int t = 0; t < d.n_towers; ++t) {
+        int H = d.in_h[t], W = d.in_w[t], C = 1, fo = 32;
+        int p0H = H, p0W = W, p0C = 1;
+        for (int i = 1; i <= d.conv_layers; ++i) {
+            n += (long)d.kh[t] * d.kw[t] * C * fo + fo + 4 * fo;
+            C = fo;
+            if (d.residual_frequency > 0 && i % d.residual_frequency == 0) {
+                if (!(p0H == H && p0W == W && p0C == C)) {
+                    if (p0C != C) n += (long)p0C * C + C;
+                    n += 4 * C;
+                }
+                n += 4 * C;
+                p0H = H; p0W = W; p0C = C;
+            }
+            if (d.pool_layer_frequency > 0 && i % d.pool_layer_frequency == 0) {
+                H /= d.pool_h[t]; W /= d.pool_w[t];
+                if (H < 1 || W < 1) { if (err) *err = "pooling collapses the activation"; return -1; }
+            }
+            if (d.feature_expand_frequency > 0 && i % d.feature_expand_frequency == 0) fo *= 2;
+        }
+        flat += H * W * C;
+    }
+    n += (long)flat * d.dense_units + d.dense_units;
+    n += (long)d.dense_units * d.output_classes + d.output_classes;
+    if (flat_out) *flat_out = flat;
+    return n;
+}
+
+extern "C" {
+
+size_t amt_rdcnn_param_count(const amt_rdcnn_desc *desc) {
+    if (!desc || desc->n_towers < 1 || desc->n_towers > 2) return 0;
+    long n = walk_count(*desc, nullptr, nullptr);
+    return n < 0 ? 0 : (size_t)n;
+}
+
+int amt_rdcnn_destroy(amt_rdcnn *net) {
+    if (!net) return AMT_OK;
+    for (float *p : net->allocs) (void)hipFree(p);
+    delete net;
+    return AMT_OK;
+}
+
+int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *wh, size_t n_floats) {
+    if (!out || !desc || !wh) return AMT_E_INVALID;
+    const amt_rdcnn_desc &d = *desc;
+    if (d.n_towers < 1 || d.n_towers > 2 || d.conv_layers < 1 || d.dense_units < 1 ||
+        d.output_classes < 1)
+        return AMT_E_INVALID;
+    int flat = 0;
+    const long need = walk_count(d, &flat, nullptr);
+    if (need < 0) return AMT_E_UNSUPPORTED;
+    if ((size_t)need != n_floats) return AMT_E_SHAPE;
+    amt_rdcnn *n = new amt_rdcnn();
+    n->d = d;
+    n->flat = flat;
+    const float *cur = wh;
+    auto take = [&](size_t k) { const float *r = cur; cur += k; return r; };
+    int rc = AMT_OK;
+#define RD_TRY(x) do { rc = (x); if (rc != AMT_OK) { amt_rdcnn_destroy(n); return rc; } } while (0)
+    for (int t = 0; t < d.n_towers; ++t) {
+        Tower tw;
+        tw.in_h = d.in_h[t]; tw.in_w = d.in_w[t]; tw.ph = d.pool_h[t]; tw.pw = d.pool_w[t];
+        int H = tw.in_h, W = tw.in_w, C = 1, fo = 32;
+        int p0H = H, p0W = W, p0C = 1;
+        tw.max_act = (size_t)H * W;
+        const int kh = d.kh[t], kw = d.kw[t];
+        for (int i = 1; i <= d.conv_layers; ++i) {
+            ConvOp c;
+            c.cin = C; c.cout = fo; c.H = H; c.W = W; c.kh = kh; c.kw = kw;
+            const float *kern = take((size_t)kh * kw * C * fo);
+            const float *bias = take(fo);
+            BN bn{take(fo), take(fo), take(fo), take(fo)};
+            std::vector<float> s, tt;
+            fold_bn(bn, fo, bias, s, tt);
+            RD_TRY(upload(n, s, &c.s1));
+            RD_TRY(upload(n, tt, &c.t1));
+            if (C == 1) {
+                std::vector<float> w1(kern, kern + (size_t)kh * kw * fo);    // [tap][cout] as is
+                RD_TRY(upload(n, w1, &c.w));
+            } else {
+                if (C % 32 || fo % 32 || !conv_supported(kh, kw) ||
+                    !((C == 32 && fo == 32) || (C == 32 && fo == 64) || (C == 64 && fo == 64) ||
+                      (C == 64 && fo == 128) || (C == 128 && fo == 128))) {
+                    amt_rdcnn_destroy(n);
+                    return AMT_E_UNSUPPORTED;
+                }
+                const int NT = fo / 32, nch = C / 32, ntap = kh * kw;
+                std::vector<float> wa((size_t)ntap * C * fo);
+                // [cchunk][tap][c][j][nt]  <-  keras [tap][cin][cout], cout = 32*nt + j
+                for (int ch = 0; ch < nch; ++ch)
+                    for (int tap = 0; tap < ntap; ++tap)
+                        for (int cc = 0; cc < 32; ++cc)
+                            for (int j = 0; j < 32; ++j)
+                                for (int nt = 0; nt < NT; ++nt)
+                                    wa[((((size_t)ch * ntap + tap) * 32 + cc) * 32 + j) * NT + nt] =
+                                        kern[((size_t)tap * C + ch * 32 + cc) * fo + nt * 32 + j];
+                RD_TRY(upload(n, wa, &c.w));
+                choose_tile(c);
+                if (c.TH == 0) { amt_rdcnn_destroy(n); return AMT_E_UNSUPPORTED; }
+            }
+            n->flops += 2.0 * H * W * (double)kh * kw * C * fo;
+            C = fo;
+            tw.max_act = std::max(tw.max_act, (size_t)H * W * C);
+            if (d.residual_frequency > 0 && i % d.residual_frequency == 0) {
+                c.residual = true;
+                if (!(p0H == H && p0W == W && p0C == C)) {
+                    ProjOp pr;
+                    pr.cin = p0C; pr.cout = C; pr.H = p0H; pr.W = p0W;
+                    pr.ph = p0H / H; pr.pw = p0W / W;            // floor(sh1/sh2), RDCNN.py:325-326
+                    pr.HO = p0H / pr.ph; pr.WO = p0W / pr.pw;    // valid avg-pool output
+                    if (pr.HO != H || pr.WO != W) { amt_rdcnn_destroy(n); return AMT_E_UNSUPPORTED; }
+                    const float *pk = nullptr, *pb = nullptr;
+                    if (p0C != C) { pk = take((size_t)p0C * C); pb = take(C); }
+                    BN sbn{take(C), take(C), take(C), take(C)};
+                    std::vector<float> ps, pt;
+                    fold_bn(sbn, C, pb, ps, pt);
+                    if (pk) { std::vector<float> pw_(pk, pk + (size_t)p0C * C); RD_TRY(upload(n, pw_, &pr.w)); }
+                    RD_TRY(upload(n, ps, &pr.s));
+                    RD_TRY(upload(n, pt, &pr.t));
+                    n->flops += 2.0 * H * W * (double)p0C * C;
+                    c.sc_proj = (int)tw.projs.size();
+                    tw.projs.push_back(pr);
+                }
+                BN rbn{take(C), take(C), take(C), take(C)};
+                std::vector<float> rs, rt;
+                fold_bn(rbn, C, nullptr, rs, rt);
+                RD_TRY(upload(n, rs, &c.s2));
+                RD_TRY(upload(n, rt, &c.t2));
+                p0H = H; p0W = W; p0C = C;
+            }
+            if (d.pool_layer_frequency > 0 && i % d.pool_layer_frequency == 0) {
+                c.pool_after = 1;
+                H /= tw.ph; W /= tw.pw;
+            }
+            if (d.feature_expand_frequency > 0 && i % d.feature_expand_frequency == 0) fo *= 2;
+            tw.convs.push_back(c);
+        }
+        tw.out_h = H; tw.out_w = W; tw.out_c = C;
+        n->towers.push_back(tw);
+    }
+    {
+        const float *k1 = take((size_t)flat * d.dense_units);
+        const float *b1 = take(d.dense_units);
+        const float *k2 = take((size_t)d.dense_units * d.output_classes);
+        const float *b2 = take(d.output_classes);
+        std::vector<float> a(k1, b1), b(b1, k2), c2(k2, b2), e(b2, cur);
+        RD_TRY(upload(n, a, &n->d1w));
+        RD_TRY(upload(n, b, &n->d1b));
+        RD_TRY(upload(n, c2, &n->d2w));
+        RD_TRY(upload(n, e, &n->d2b));
+        n->flops += 2.0 * flat * d.dense_units + 2.0 * d.dense_units * d.output_classes;
+    }
+#undef RD_TRY
+    if ((size_t)(cur - wh) != n_floats) { amt_rdcnn_destroy(n); return AMT_E_SHAPE; }
+    *out = n;
+    return AMT_OK;
+}
+
+double amt_rdcnn_flops_per_window(const amt_rdcnn *net) { return net ? net->flops : 0.0; }
+
+#define RD_CHUNK 512
+static size_t ws_floats(const amt_rdcnn *n, int Bc) {
+    size_t ma = 0;
+    for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);
+    ma = (ma + 3) & ~(size_t)3;
+    return (size_t)Bc * (4 * ma + (size_t)((n->flat + 3) & ~3) + (size_t)((n->d.dense_units + 3) & ~3) +
+                         (size_t)((n->d.output_classes + 3) & ~3));
+}
+
+size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B) {
+    if (!net || B <= 0) return 0;
+    return ws_floats(net, std::min(B, RD_CHUNK)) * sizeof(float);
+}
+
+static int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)std::min<size_t>(g, 65536);
+}
+
+int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float *y, float *logits,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+    if (!net || !x || !y || !workspace || B <= 0) return AMT_E_INVALID;
+    const amt_rdcnn_desc &d = net->d;
+    for (int t = 0; t < d.n_towers; ++t) if (!x[t]) return AMT_E_INVALID;
+    if (workspace_bytes < amt_rdcnn_workspace_bytes(net, B)) return AMT_E_NOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    size_t ma = 0;
+    for (const Tower &t : net->towers) ma = std::max(ma, t.max_act);
+    ma = (ma + 3) & ~(size_t)3;
+    const int K = d.output_classes, DU = d.dense_units, flat = net->flat;
+
+    for (int b0 = 0; b0 < B; b0 += RD_CHUNK) {
+        const int Bc = std::min(RD_CHUNK, B - b0);
+        float *ws = static_cast<float *>(workspace);
+        float *buf[4];
+        for (int i = 0; i < 4; ++i) buf[i] = ws + (size_t)i * Bc * ma;
+        float *flatbuf = ws + (size_t)4 * Bc * ma;
+        float *d1 = flatbuf + (size_t)Bc * ((flat + 3) & ~3);
+        float *lg = d1 + (size_t)Bc * ((DU + 3) & ~3);
+        int flat_off = 0;
+        for (int t = 0; t < d.n_towers; ++t) {
+            const Tower &tw = net->towers[t];
+            const float *cur = x[t] + (size_t)b0 * tw.in_h * tw.in_w;
+            size_t cur_stride = (size_t)tw.in_h * tw.in_w;
+            const float *p0 = cur; size_t p0_stride = cur_stride;
+            int H = tw.in_h, W = tw.in_w;
+            const int L = (int)tw.convs.size();
+            auto pick = [&](const float *a, const float *b_, const float *c_) -> float * {
+                for (int i = 0; i < 4; ++i)
+                    if (buf[i] != a && buf[i] != b_ && buf[i] != c_) return buf[i];
+                return nullptr;
+            };
+            for (int i = 0; i < L; ++i) {
+                const ConvOp &c = tw.convs[i];
+                const bool last_op = (i == L - 1) && !c.pool_after;
+                float *o = last_op ? flatbuf + flat_off : pick(cur, p0, nullptr);
+                const size_t o_stride = last_op ? (size_t)flat : (size_t)H * W * c.cout;
+                const float *sc = nullptr; size_t sc_stride = 0;
+                if (c.residual) {
+                    if (c.sc_proj >= 0) {
+                        const ProjOp &pr = tw.projs[c.sc_proj];
+                        float *sb = pick(cur, p0, o);
+                        ProjParams pp{p0, p0_stride, sb, (size_t)pr.HO * pr.WO * pr.cout, pr.w, pr.s, pr.t,
+                                      Bc, pr.H, pr.W, pr.cin, pr.cout, pr.ph, pr.pw, pr.HO, pr.WO};
+                        proj_kernel<<<grid_for((size_t)Bc * pr.HO * pr.WO * pr.cout), 256, 0, st>>>(pp);
+                        sc = sb; sc_stride = (size_t)pr.HO * pr.WO * pr.cout;
+                    } else {
+                        sc = p0; sc_stride = p0_stride;
+                    }
+                }
+                if (c.cin == 1) {
+                    Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
+                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
+                                   Bc, H, W, c.kh, c.kw, c.cout};
+                    const size_t lds = (size_t)c.kh * c.kw * c.cout * 4;
+                    const int ppb = 256 / c.cout;
+                    const size_t blocks = ((size_t)Bc * H * W + ppb - 1) / ppb;
+                    conv1_kernel<<<(unsigned)std::min<size_t>(blocks, 1u << 20), 256, lds, st>>>(cp);
+                    AMT_LAUNCH_CHECK();
+                } else {
+                    ConvParams cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
+                                  c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
+                                  Bc, H, W, c.TH, c.TW, c.NWIN, (H + c.TH - 1) / c.TH,
+                                  (W + c.TW - 1) / c.TW};
+                    const int rc = launch_conv(c, cp, st);
+                    if (rc != AMT_OK) return rc;
+                }
+                if (c.residual) { p0 = o; p0_stride = o_stride; }
+                cur = o; cur_stride = o_stride;
+                if (c.pool_after) {
+                    const int HO = H / tw.ph, WO = W / tw.pw;
+                    const bool last = (i == L - 1);
+                    float *po = last ? flatbuf + flat_off : pick(cur, p0, nullptr);
+                    const size_t po_stride = last ? (size_t)flat : (size_t)HO * WO * c.cout;
+                    maxpool_kernel<<<grid_for((size_t)Bc * HO * WO * c.cout), 256, 0, st>>>(
+                        cur, cur_stride, po, po_stride, Bc, H, W, c.cout, tw.ph, tw.pw, HO, WO);
+                    cur = po; cur_stride = po_stride; H = HO; W = WO;
+                }
+            }
+            flat_off += tw.out_h * tw.out_w * tw.out_c;
+        }
+        dense_kernel<<<dim3((DU + 255) / 256, (Bc + DN_MB - 1) / DN_MB), 256, 0, st>>>(
+            flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1);
+        dense_kernel<<<dim3((K + 255) / 256, (Bc + DN_MB - 1) / DN_MB), 256, 0, st>>>(
+            d1, DU, net->d2w, net->d2b, K, lg, Bc, 0);
+        head_output_kernel<<<(Bc + 63) / 64, 64, 0, st>>>(lg, y + (size_t)b0 * K, Bc, K, d.out_lo, d.out_hi);
+        if (logits)
+            AMT_HIP_CHECK(hipMemcpyAsync(logits + (size_t)b0 * K, lg, (size_t)Bc * K * sizeof(float),
+                                         hipMemcpyDeviceToDevice, st));
+        AMT_LAUNCH_CHECK();
+    }
+    return AMT_OK;
+}
+
+}  // extern "C"

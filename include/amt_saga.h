@@ -1,0 +1,196 @@
+/*
+ * amt_saga.h -- C ABI of the MI355X (gfx950) hot path of AMT-SAGA.
+ *
+ * Drop-in boundary.  The reference (RobertKajnak/AMT-SAGA) is pure Python and
+ * has no FFI; the boundary it does have is the object surface that
+ * training.py calls.  Each entry point below names the
+ * reference interface it replaces (paths relative to the upstream repo).  The
+ * Python host shim in amt-saga_amd/amt_saga binds these with ctypes and keeps
+ * the reference's class / method names on top.
+ *
+ * Conventions
+ *   - every function returns an int status: AMT_OK (0) or a negative AMT_E_*;
+ *     no exceptions cross the ABI.  amt_strerror() gives the text the Python
+ *     shim raises as ValueError / RuntimeError (the reference raises
+ *     ValueError, util_train_test.py:109-112, util_audio.py:207,505).
+ *   - all data pointers are DEVICE pointers owned by the caller; sizes are
+ *     explicit; `stream` is a hipStream_t passed as void*.  Calls enqueue work
+ *     and return; nothing synchronises the device except amt_*_create.
+ *   - spectra are FRAME-MAJOR in HBM:  spec[b][t][f], f contiguous, row pitch
+ *     `ldf` floats (ldf >= n_fft/2+1, multiple of 4), window pitch
+ *     `spec_stride` elements.  The reference's numpy layout is [f][t]; the
+ *     Python shim transposes at the boundary.  Pad columns f in [F, ldf) are
+ *     written as zero by every producer.
+ *   - no hidden global state besides the handles returned by *_create.
+ */
+#ifndef AMT_SAGA_H
+#define AMT_SAGA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMT_OK            0
+#define AMT_E_INVALID    -1   /* bad argument (null pointer, non power-of-two n_fft, ...) */
+#define AMT_E_SHAPE      -2   /* shape mismatch ("Invalid Input shape", util_train_test.py:109) */
+#define AMT_E_HIP        -3   /* a HIP runtime call failed; see amt_last_hip_error() */
+#define AMT_E_NOMEM      -4
+#define AMT_E_UNSUPPORTED -5  /* topology / size outside what the kernels are built for */
+#define AMT_E_ATTRIB     -6   /* "Requested attribute does not exist" (util_audio.py:207) */
+
+int         amt_version(void);                 /* ABI version, currently 1 */
+const char *amt_strerror(int status);
+const char *amt_last_hip_error(void);          /* text of the last failing HIP call (thread-local) */
+int         amt_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
+
+/* ------------------------------------------------------------------------ *
+ * STFT / iSTFT   (replaces librosa.stft / magphase / istft as called from
+ * audio_complete.F / .mag / .ph / .wf, util_audio.py:88-168)
+ * ------------------------------------------------------------------------ */
+typedef struct amt_stft_plan amt_stft_plan;
+
+/* n_fft: power of two in [256, 4096]; hop > 0; center as librosa (reflect pad
+ * n_fft/2).  Uploads the twiddle / window table (computed in double). */
+int amt_stft_plan_create(amt_stft_plan **plan, int n_fft, int hop, int center);
+int amt_stft_plan_destroy(amt_stft_plan *plan);
+/* frames produced for a signal of L samples: center ? 1 + L/hop : 1 + (L-n_fft)/hop */
+int amt_stft_frames(const amt_stft_plan *plan, int L);
+
+/* audio_complete.mag / .ph / .ref_mag (util_audio.py:139-174) in one pass:
+ *   wave  [B][wave_stride]  f32, L valid samples per window
+ *   mag   [B][T][ldf]       f32 = |STFT|
+ *   phase [B][T][ldf]       float2 = exp(i*angle(STFT)) (1+0i where STFT == 0); may be NULL
+ *   ref_max [B]             f32 = max(mag) per window (np.max(self.mag), :173); may be NULL
+ * T must equal amt_stft_frames(plan, L). */
+int amt_stft_mag(const amt_stft_plan *plan, const float *wave, int B, int L,
+                 size_t wave_stride, float *mag, float *phase_ri, float *ref_max,
+                 int T, int ldf, size_t spec_stride, void *stream);
+
+/* audio_complete.wf getter, the `mag * ph -> librosa.istft` branch
+ * (util_audio.py:94-97): wave_out[b][0 .. hop*(T-1)) f32.  phase_ri may be
+ * NULL (then `mag` is taken as interleaved complex F with pitch 2*ldf). */
+int amt_istft(const amt_stft_plan *plan, const float *mag, const float *phase_ri,
+              int B, int T, int ldf, size_t spec_stride, float *wave_out,
+              size_t wave_stride, void *stream);
+
+/* np.max over each window's [T][ldf] block (audio_complete.ref_mag, :170-174) */
+int amt_window_max(const float *spec, int B, int T, int ldf, size_t spec_stride,
+                   float *out_max, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Spectral subtraction  (replaces audio_complete.subtract, util_audio.py:221-259)
+ * ------------------------------------------------------------------------ */
+typedef struct amt_subtract_args {
+    float       *resid;          /* [B][T][ldf] in place (self.mag)                          */
+    const float *resid_max;      /* [B] current ref_mag of each window, or NULL              */
+    const float *guess;          /* base of the guess magnitudes, frame-major [.][Tg][ldf]   */
+    const float *guess_max;      /* [n_guess] ref_mag of each guess, or NULL                 */
+    const int32_t *guess_index;  /* [B] which guess each window subtracts; NULL => b         */
+    const int32_t *guess_frames; /* [B] frames of each window's guess; NULL => guess_frames_all */
+    const int32_t *offset_frames;/* [B] first frame (already max(..-attack_compensation,0));
+                                    NULL => 0                                                */
+    float       *new_max;        /* [B] out: np.max(self.mag) after the step, or NULL        */
+    size_t       resid_stride;   /* elements between windows                                 */
+    size_t       guess_stride;   /* elements between guesses                                 */
+    int32_t      B, T, ldf, F;
+    int32_t      guess_frames_all;
+    int32_t      normalize;      /* scale by resid_max/guess_max (needs both arrays)         */
+    int32_t      relu;
+    float        overkill_factor;
+} amt_subtract_args;
+
+int amt_subtract(const amt_subtract_args *args, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Feature gathers (audio_complete.compress_bands :436-466, ._resize :384-409,
+ * .resize :469-507, .section_power :334-349 and the recipe of
+ * training.py:333-363).  Outputs are the NHWC head inputs [B][bands][frames].
+ * ------------------------------------------------------------------------ */
+/* C_timing = _resize(compress_bands(mag, bands), target) / ref   (training.py:333-336)
+ *   edges [bands+1] int32 device (row ranges over f: util_audio.py:451-456)
+ *   ref [B] device or NULL (=> 1): the song-level ref_mag the recipe divides by
+ *   src_frame [target_frames] device or NULL (=> identity): source frame of every
+ *   output column (-1 => zero column), i.e. _resize's tile/crop rule as a table
+ *   out [B][bands][target_frames] f32 */
+int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
+                       const int32_t *edges, int bands, const float *ref,
+                       const int32_t *src_frame, float *out, int target_frames,
+                       void *stream);
+
+/* short-window gather: for every window b take frames src_frame[b][0..frames)
+ * (-1 => zeros; the table realises _resize's tile/crop rule) and rows
+ * [band_min[b], band_min[b]+bands) (zero past F; band_min NULL => 0):
+ *   mode 0: out = mag / ref[b]  (ref NULL => 1)             (F_sw_inst_foc / _const, :350,:360)
+ *   mode 1: out = log10(mag*1000+1) / max over the window  (.._log10, :353-354,:358-359)
+ *   mode 2: out = (angle(phase)+3.15)/6.3                  (ph, :361-362)
+ * out [B][bands][frames] f32. */
+int amt_short_window(const float *mag, const float *phase_ri, int B, int T, int F,
+                     int ldf, size_t spec_stride, const int32_t *src_frame,
+                     int frames, const int32_t *band_min, int bands,
+                     const float *ref, int mode, float *out, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Constant-Q slices (replaces audio_complete.slice_C, util_audio.py:411-434,
+ * i.e. |librosa.cqt| evaluated only at the frames _resize keeps).  The
+ * transform is the build's own spec (oracle/cqt.py); parity vs librosa is
+ * unpinned.
+ * ------------------------------------------------------------------------ */
+typedef struct amt_cqt_args {
+    const float   *wave;        /* [B][wave_stride], L valid samples                    */
+    const int32_t *src_frame;   /* [B][frames] STFT-frame index of each output column, -1 => zeros */
+    const int32_t *bin0;        /* [B] first bin of the table for each window, or NULL => 0 */
+    const uint32_t *phase_inc;  /* [n_table] per-bin frequency, cycles/sample * 2^32    */
+    const int32_t *length;      /* [n_table] filter length N_k in samples               */
+    const float   *ref;         /* [B] divisor (ref_C_*, training.py:340-388) or NULL    */
+    float         *out;         /* [B][n_bins][frames]                                   */
+    size_t         wave_stride;
+    int32_t        B, L, hop, frames, n_bins, n_table;
+} amt_cqt_args;
+
+int amt_cqt_slices(const amt_cqt_args *args, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * RDCNN forward (replaces res_net.predict, RDCNN.py:591-597, for the graph
+ * built by RDCNN.py:176-233).
+ * ------------------------------------------------------------------------ */
+typedef struct amt_rdcnn amt_rdcnn;
+
+typedef struct amt_rdcnn_desc {
+    int32_t n_towers;                    /* 1 or 2 (instrument_dual)                    */
+    int32_t in_h[2], in_w[2];            /* input_shapes (bands, frames), Cin = 1        */
+    int32_t kh[2], kw[2];                /* kernel_sizes                                 */
+    int32_t pool_h[2], pool_w[2];        /* pool_sizes                                   */
+    int32_t conv_layers;                 /* convolutional_layer_count                    */
+    int32_t feature_expand_frequency;
+    int32_t pool_layer_frequency;
+    int32_t residual_frequency;          /* residual_layer_frequencies = [r]; 0 = none   */
+    int32_t dense_units;                 /* 300                                          */
+    int32_t output_classes;              /* 1 => sigmoid + range scaling; >1 => softmax  */
+    float   out_lo, out_hi;              /* output_range                                 */
+} amt_rdcnn_desc;
+
+/* Weights: one host blob of f32 in the canonical order documented in
+ * amt-saga_amd/amt_saga/rdcnn.py (pack_weights); n_floats is checked against
+ * the descriptor.  Uploads and pre-arranges them for the MFMA kernels. */
+int amt_rdcnn_create(amt_rdcnn **net, const amt_rdcnn_desc *desc,
+                     const float *weights_host, size_t n_floats);
+int amt_rdcnn_destroy(amt_rdcnn *net);
+size_t amt_rdcnn_param_count(const amt_rdcnn_desc *desc);
+/* device scratch needed for a batch of B windows */
+size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B);
+/* x[t]: [B][in_h][in_w] f32 (NHWC with C = 1) per tower; y: [B][output_classes] f32
+ * (scaled regression value or softmax probabilities); logits (optional, may be
+ * NULL): [B][output_classes] pre-activation of the last Dense. */
+int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B,
+                      float *y, float *logits, void *workspace,
+                      size_t workspace_bytes, void *stream);
+/* FLOPs (2*MAC) of one window's forward, for roofline accounting */
+double amt_rdcnn_flops_per_window(const amt_rdcnn *net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_SAGA_H */

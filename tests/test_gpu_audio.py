@@ -1,0 +1,259 @@
+"""GPU parity: HIP STFT / magphase / iSTFT / subtract / features vs the oracle,
+the reference-emitted golden vectors and the recorded FLAC triples.  All calls
+go through the C ABI (ctypes) -- no CPU fallback exists in the product path."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4      # north_star tolerance: relative to the window maximum
+
+
+def _relmax(a, b):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(
+        np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from amt_saga import audio, _lib
+    _lib.load()
+    from oracle import audio as oa
+    return audio, oa
+
+
+def _signal(L, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / 44100.0
+    y = 0.5 * np.sin(2 * np.pi * 220.0 * t) + 0.3 * np.sin(2 * np.pi * 1333.7 * t + 1.0)
+    y += 0.05 * rng.standard_normal(L)
+    y *= np.exp(-t * 1.5)
+    return y.astype(np.float32)
+
+
+@pytest.mark.parametrize('n_fft,L', [(256, 1000), (512, 4096), (1024, 5000), (2048, 263680 // 8),
+                                     (2048, 20000), (4096, 4096 * 6 + 17), (4096, 132300)])
+def test_stft_mag_phase_max(mods, n_fft, L):
+    audio, oa = mods
+    B = 3
+    wave = np.stack([_signal(L, s) for s in range(B)])
+    b = audio.AudioBatch(wave, n_fft).stft(True)
+    mag = b.mag.cpu().numpy()
+    ph = b.ph.cpu().numpy()
+    rmax = b.ref_max.cpu().numpy()
+    Fb = n_fft // 2 + 1
+    for i in range(B):
+        F = oa.stft(wave[i], n_fft)
+        m_ref, p_ref = oa.magphase(F)
+        assert mag[i].shape[0] == F.shape[1]
+        assert _relmax(mag[i][:, :Fb].T, m_ref) < REL
+        assert np.all(mag[i][:, Fb:] == 0)
+        # phase: compare where the magnitude is not negligible (angle is ill-conditioned at 0)
+        sel = m_ref > 1e-3 * m_ref.max()
+        pc = (ph[i][:, :Fb, 0] + 1j * ph[i][:, :Fb, 1]).T
+        assert np.abs(pc - p_ref)[sel].max() < 2e-3
+        assert np.abs(np.abs(pc) - 1).max() < 1e-5
+        assert abs(rmax[i] - mag[i].max()) == 0
+        assert abs(rmax[i] - m_ref.max()) / m_ref.max() < REL
+
+
+def test_stft_edge_cases(mods):
+    audio, oa = mods
+    # silence -> mag 0, phase 1+0i (magphase of 0), max 0
+    b = audio.AudioBatch(np.zeros((1, 3000), np.float32), 512).stft(True)
+    assert float(b.mag.abs().max()) == 0.0
+    ph = b.ph.cpu().numpy()[0][:, :257]
+    assert np.all(ph[..., 0] == 1) and np.all(ph[..., 1] == 0)
+    assert float(b.ref_max[0]) == 0.0
+    # too short for the reflect padding -> ValueError (shape), like numpy.pad would refuse
+    with pytest.raises(ValueError):
+        audio.AudioBatch(np.zeros((1, 100), np.float32), 512).stft()
+    # unsupported FFT size
+    with pytest.raises(ValueError):
+        audio.AudioBatch(np.zeros((1, 3000), np.float32), 300)
+
+
+@pytest.mark.parametrize('n_fft,T', [(512, 37), (2048, 64), (2048, 65), (4096, 130)])
+def test_istft_vs_oracle_and_roundtrip(mods, n_fft, T):
+    audio, oa = mods
+    hop = n_fft // 4
+    L = hop * (T - 1)
+    wave = np.stack([_signal(L, 10 + s) for s in range(2)])
+    b = audio.AudioBatch(wave, n_fft).stft(True)
+    assert b.T == T
+    y = b.istft().cpu().numpy()
+    assert y.shape == (2, L)
+    # STFT -> iSTFT is the identity (COLA, hann, hop = N/4)
+    assert _relmax(y, wave) < REL
+    # modified spectrogram (not a consistent STFT): compare with the oracle's istft
+    import torch
+    b.mag *= torch.linspace(0.2, 1.0, b.mag.shape[2], device=b.mag.device)
+    y2 = b.istft().cpu().numpy()
+    Fb = n_fft // 2 + 1
+    for i in range(2):
+        m = b.mag[i].cpu().numpy()[:, :Fb].T
+        p = b.ph[i].cpu().numpy()
+        pc = (p[:, :Fb, 0] + 1j * p[:, :Fb, 1]).T
+        ref = oa.istft(m * pc, hop)
+        assert _relmax(y2[i], ref) < REL
+
+
+def test_subtract_golden_bit_exact(mods, refvec):
+    """amt_subtract vs the reference's own subtract() outputs: bit-exact."""
+    audio, oa = mods
+    n = int(refvec['sub_cases'])
+    for c in range(n):
+        n_fft, off_s, acomp, norm, relu, overkill = refvec['sub%d_args' % c]
+        n_fft = int(n_fft)
+        Tm = refvec['sub%d_mix' % c].shape[1]
+        hop = n_fft // 4
+        ac = audio.audio_complete(np.zeros(hop * (Tm - 1), np.float32), n_fft)
+        ac._mag = refvec['sub%d_mix' % c].copy()
+        g = audio.audio_complete(np.zeros(hop * (refvec['sub%d_guess' % c].shape[1] - 1), np.float32), n_fft)
+        g._mag = refvec['sub%d_guess' % c].copy()
+        ac.subtract(g, offset=float(off_s), attack_compensation=int(acomp),
+                    normalize=bool(norm), relu=bool(relu), overkill_factor=float(overkill))
+        out = ac.mag
+        exp = refvec['sub%d_out' % c]
+        assert out.dtype == np.float32 and exp.dtype == np.float32
+        assert np.array_equal(out, exp), 'case %d max diff %g' % (c, np.abs(out - exp).max())
+        # invalidation state (util_audio.py:149-157)
+        assert ac._wf is None and ac._F is None and ac._D is None and ac._ref_mag is None
+        assert ac.ref_mag == exp.max()
+    # raw ndarray subtrahend
+    ac = audio.audio_complete(np.zeros(512 * 23, np.float32), 2048)
+    ac._mag = refvec['subraw_mix'].copy()
+    ac.subtract(refvec['subraw_guess'].copy(), offset=0.05)
+    assert np.array_equal(ac.mag, refvec['subraw_out'])
+    # offset beyond the window: the reference raises ValueError
+    ac = audio.audio_complete(np.zeros(64 * 39, np.float32), 256)
+    ac._mag = np.ones((129, 40), np.float32)
+    with pytest.raises(ValueError):
+        ac.subtract(np.ones((129, 13), np.float32), offset=10.0)
+
+
+def test_subtract_batched_bank(mods):
+    """Batched form: guess bank + per-window index / offset / length vs the oracle loop."""
+    audio, oa = mods
+    import torch
+    rng = np.random.default_rng(5)
+    n_fft, B, T, G, Tg = 512, 7, 50, 4, 12
+    Fb, ldf = 257, audio.ldf_of(512)
+    mix = (rng.random((B, Fb, T)) ** 2).astype(np.float32)
+    bank = (rng.random((G, Fb, Tg)) ** 2).astype(np.float32)
+    idx = rng.integers(0, G, B).astype(np.int32)
+    off = np.array([0, 3, 38, 45, 49, 50, 10], np.int32)     # 49/50: clipped to <=1/0 frames
+    gl = np.array([12, 5, 12, 12, 12, 12, 0], np.int32)      # ragged guess lengths incl. empty
+    b = audio.AudioBatch(None, n_fft)
+    hm = np.zeros((B, T, ldf), np.float32); hm[:, :, :Fb] = mix.transpose(0, 2, 1)
+    hb = np.zeros((G, Tg, ldf), np.float32); hb[:, :, :Fb] = bank.transpose(0, 2, 1)
+    b.mag = torch.from_numpy(hm).cuda()
+    b.ref_max = b.window_max()
+    assert np.array_equal(b.ref_max.cpu().numpy(), mix.max(axis=(1, 2)))
+    gmax = torch.from_numpy(bank.max(axis=(1, 2))).cuda()
+    b.subtract(torch.from_numpy(hb).cuda(), gmax, torch.from_numpy(idx).cuda(),
+               torch.from_numpy(gl).cuda(), torch.from_numpy(off).cuda(), True, True, 1.0)
+    out = b.mag.cpu().numpy()[:, :, :Fb].transpose(0, 2, 1)
+    for i in range(B):
+        exp = mix[i].copy()
+        g = bank[idx[i]][:, :gl[i]].copy()
+        g *= exp.max() / bank[idx[i]].max()
+        n = max(0, min(gl[i], T - off[i]))
+        exp[:, off[i]:off[i] + n] -= g[:, :n]
+        exp = np.maximum(exp, 0)
+        assert np.array_equal(out[i], exp), i
+        assert float(b.ref_max[i]) == exp.max()
+
+
+@pytest.mark.parametrize('name', ['piano', 'strings-piano', 'overdriven'])
+def test_flac_triples_through_hip(mods, golden_dir, name):
+    """The reference's recorded librosa outputs (subtraction_demo) through the HIP
+    chain STFT -> subtract -> iSTFT: within PCM-24 quantisation + fp32 FFT error."""
+    audio, oa = mods
+    z = np.load(os.path.join(golden_dir, 'subtraction_demo_%s.npz' % name))
+    sc = 1.0 / (1 << 23)
+    mix, guess, sub = z['mix'] * sc, z['guess'] * sc, z['sub'] * sc
+    a = audio.audio_complete(mix, int(z['n_fft']))
+    g = audio.audio_complete(guess, int(z['n_fft']))
+    a.subtract(g, offset=float(z['offset_s']), attack_compensation=int(z['attack_compensation']),
+               normalize=bool(z['normalize']))
+    y = a.wf
+    assert y.shape == sub.shape
+    m = np.abs(sub) < 0.999            # the recorded file clips at +-1.0
+    assert np.abs(y - sub)[m].max() < 2e-5
+
+
+def test_compress_bands_and_short_window(mods, refvec):
+    audio, oa = mods
+    import torch
+    for Fb in (1025, 2049):
+        S = refvec['cb_in_%d' % Fb]
+        out = audio.audio_complete.compress_bands(S, bands=20)
+        assert out.shape == (20, S.shape[1])
+        assert _relmax(out, refvec['cb_out_%d' % Fb]) < 1e-6
+    out = audio.audio_complete.compress_bands(refvec['cb_lin_in'], bands=8, log=False)
+    assert _relmax(out, refvec['cb_lin_out']) < 1e-6
+    # batched C_timing with reference division and a resize table
+    rng = np.random.default_rng(3)
+    n_fft, B, T = 2048, 3, 21
+    wave = np.stack([_signal(512 * (T - 1), 30 + s) for s in range(B)])
+    b = audio.AudioBatch(wave, n_fft).stft(True)
+    ref = b.ref_max.clone()
+    ct = b.compress_bands(20, ref, 32).cpu().numpy()
+    for i in range(B):
+        m = b.mag[i].cpu().numpy()[:, :1025].T
+        exp = oa.AudioCompleteOracle._resize(oa.AudioCompleteOracle.compress_bands(m, 20), 32) / m.max()
+        assert _relmax(ct[i], exp) < 1e-5
+    # short windows: three modes vs the oracle recipe (training.py:347-363)
+    src = np.stack([audio.resize_source_frames(t, 8) + s for t, s in ((3, 2), (11, 5), (0, 0))]).astype(np.int32)
+    src[2] = -1
+    lo = np.array([11, 700, 40], np.int32)
+    srcd, lod = torch.from_numpy(src).cuda(), torch.from_numpy(lo).cuda()
+    f0 = b.short_window(srcd, lod, 348, ref, 0).cpu().numpy()
+    f1 = b.short_window(srcd, lod, 348, None, 1).cpu().numpy()
+    f2 = b.short_window(srcd, lod, 348, None, 2).cpu().numpy()
+    for i in range(B):
+        m = b.mag[i].cpu().numpy()[:, :1025].T
+        p = b.ph[i].cpu().numpy()
+        pc = (p[:, :1025, 0] + 1j * p[:, :1025, 1]).T
+        cols = src[i]
+        sw = np.where(cols[None, :] >= 0, m[:, np.maximum(cols, 0)], 0)
+        swp = np.where(cols[None, :] >= 0, pc[:, np.maximum(cols, 0)], 0)
+        band = np.zeros((348, 8), np.float32); bandp = np.zeros((348, 8), np.complex64)
+        hi = min(1025, lo[i] + 348)
+        band[:hi - lo[i]] = sw[lo[i]:hi]; bandp[:hi - lo[i]] = swp[lo[i]:hi]
+        assert _relmax(f0[i], band / m.max()) < 1e-6
+        lg = np.log10(band * 1000 + 1)
+        if lg.max() > 0:
+            assert _relmax(f1[i], lg / lg.max()) < 1e-5
+        else:
+            assert np.all(np.isnan(f1[i]))          # 0/0, as in the reference
+        assert np.abs(f2[i] - (np.angle(bandp) + 3.15) / 6.3).max() < 2e-4
+
+
+def test_audio_complete_surface(mods):
+    """Property cache / invalidation behaves like the reference object."""
+    audio, oa = mods
+    wf = _signal(1024 * 40, 77)
+    a = audio.audio_complete(wf, 4096)
+    o = oa.AudioCompleteOracle(wf, 4096)
+    assert a.shape == o.shape == (2049, 41)
+    assert _relmax(a.mag, o.mag) < REL
+    assert abs(a.ref_mag - o.ref_mag) / o.ref_mag < REL
+    assert a._seconds_to_frames(0.5) == o._seconds_to_frames(0.5)
+    assert a.midi_tone_to_FFT(60) == o.midi_tone_to_FFT(60) == 23
+    assert _relmax(np.abs(a.F), np.abs(o.F)) < REL
+    s = a.section(0.1, None, 20); so = o.section(0.1, None, 20)
+    assert s.shape == so.shape and _relmax(s.mag, so.mag) < REL
+    r = a.resize(0.2, 0.1, 8, attribs=['mag', 'ph']); ro = o.resize(0.2, 0.1, 8, attribs=['mag', 'ph'])
+    assert r.shape == ro.shape == (2049, 8) and _relmax(r.mag, ro.mag) < REL
+    c = a.clone(); c.mag = c.mag * 0.5
+    assert c._wf is None and c._ref_mag is None and _relmax(c.wf, 0.5 * wf[:1024 * 40]) < 2e-4
+    with pytest.raises(ValueError):
+        a._P('nope')
+    with pytest.raises(ValueError):
+        a.resize(0, 0.1, 8, attribs=['zzz'])

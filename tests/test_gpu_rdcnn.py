@@ -1,0 +1,168 @@
+"""GPU parity: HIP RDCNN forward (fp32 MFMA implicit GEMM) and CQT slices vs the
+numpy oracle on shared synthetic weights / seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    from amt_saga import _lib, heads, hyperparams, rdcnn, audio
+    _lib.load()
+    from oracle import rdcnn as orc, cqt as ocqt
+    return dict(torch=torch, heads=heads, hp=hyperparams, rdcnn=rdcnn, orc=orc, ocqt=ocqt,
+                audio=audio)
+
+
+def _inputs(shape, B, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.random((B,) + tuple(shape)) ** 2).astype(np.float32)
+
+
+def _check_head(env, head, cfg, B, seed, near_tie=0.02):
+    xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
+    dev = [env['torch'].from_numpy(x).cuda() for x in xs]
+    y, lg = head.predict_device(dev, return_logits=True)
+    y, lg = y.cpu().numpy(), lg.cpu().numpy()
+    ref_lg = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float32,
+                                return_logits=True)
+    ref = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float32)
+    ref64 = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float64)
+    scale = max(np.abs(ref_lg).max(), 1.0)
+    assert np.abs(lg - ref_lg).max() / scale < REL, np.abs(lg - ref_lg).max()
+    assert np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30) < REL
+    # the fp32 GPU result is as close to the fp64 truth as the fp32 CPU result is (x4 slack)
+    e_gpu = np.abs(y - ref64).max()
+    e_cpu = np.abs(ref - ref64).max()
+    assert e_gpu <= 4 * e_cpu + 1e-5 * max(np.abs(ref64).max(), 1.0)
+    # predicted integer indices: bit-exact away from rounding ties (SURVEY 7 hard part 4)
+    if cfg['output_classes'] == 1:
+        frac = np.abs(ref64 - np.floor(ref64) - 0.5)
+        safe = frac[:, 0] > near_tie
+        assert np.array_equal(np.rint(y)[safe], np.rint(ref)[safe])
+        assert np.array_equal(np.rint(y)[safe], np.rint(ref64)[safe])
+    else:
+        top2 = np.sort(ref64, axis=1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert np.array_equal(np.argmax(y, 1)[safe], np.argmax(ref64, 1)[safe])
+        assert np.abs(y.sum(1) - 1).max() < 1e-5
+    return y
+
+
+def test_velocity_head(env):
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].VelocityClassifier(p)
+    cfg = env['orc'].head_config(p, 'velocity')
+    assert cfg['convolutional_layer_count'] == 11
+    _check_head(env, h, cfg, 5, 1)
+
+
+def test_pitch_head(env):
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].pitch_classifier(p)
+    cfg = env['orc'].head_config(p, 'pitch')
+    y = _check_head(env, h, cfg, 3, 2)
+    assert y.shape == (3, 1) and np.all((y >= 21) & (y <= 108))
+
+
+def test_instrument_head_and_dual(env):
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].InstrumentClassifier(p, 'instrument')
+    _check_head(env, h, env['orc'].head_config(p, 'instrument'), 2, 3)
+    hd = env['heads'].InstrumentClassifier(p, 'instrument_dual')
+    _check_head(env, hd, env['orc'].head_config(p, 'instrument_dual'), 2, 4)
+    with pytest.raises(ValueError):
+        env['heads'].InstrumentClassifier(p, 'nope')
+
+
+def test_timing_head_n4096(env):
+    """timing head at the reference default N=4096 (20 x 258 input)."""
+    p = env['hp'].Hyperparams(N=4096)
+    h = env['heads'].timming_classifier(p)
+    cfg = env['orc'].head_config(p, 'timing')
+    assert cfg['input_shapes'][0] == (20, 258, 1)
+    _check_head(env, h, cfg, 2, 5)
+
+
+def test_timing_head_n2048_batch_independent(env):
+    """Metric configuration (20 x 516).  One window vs the oracle, then the
+    size-independent property at a larger batch: a window's output does not
+    depend on its position in the batch / workgroup window-group."""
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].timming_classifier(p)
+    cfg = env['orc'].head_config(p, 'timing')
+    _check_head(env, h, cfg, 1, 6)
+    torch = env['torch']
+    x = torch.from_numpy(_inputs((20, 516), 13, 7)).cuda()
+    y = h.predict_device([x]).cpu().numpy()
+    perm = np.random.default_rng(0).permutation(13)
+    y2 = h.predict_device([x[torch.from_numpy(perm).cuda()].contiguous()]).cpu().numpy()
+    assert np.array_equal(y[perm], y2)
+    y3 = h.predict_device([x[:1].contiguous()]).cpu().numpy()
+    assert np.array_equal(y[:1], y3)
+
+
+def test_classify_contract(env):
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].VelocityClassifier(p)
+    spec = [np.random.default_rng(i).random((36, 8)).astype(np.float32) for i in range(4)]
+    y = h.classify(spec)                       # list of 2-D arrays, gold None -> predict
+    assert y.shape == (4, 1)
+    y1 = h.classify(spec[0])                   # single 2-D array
+    assert np.array_equal(y1, y[:1])
+    with pytest.raises(ValueError) as e:
+        h.classify([np.zeros((35, 8), np.float32)])
+    assert 'Invalid Input shape. Expected: (36, 8) . Got: (35, 8)' in str(e.value)
+    with pytest.raises(NotImplementedError):
+        h.classify(spec, [1, 2, 3, 4])
+
+
+def test_cqt_slices(env):
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr, hop, L = 44100, 512, 40000
+    rng = np.random.default_rng(9)
+    t = np.arange(L) / sr
+    waves = []
+    for f0 in (110.0, 440.0, 1567.98):
+        y = sum(np.sin(2 * np.pi * f0 * h * t) / h for h in range(1, 6))
+        waves.append((y * np.exp(-2 * t) + 0.01 * rng.standard_normal(L)).astype(np.float32))
+    wave = np.stack(waves)
+    for fmin_midi, n_bins, bpo in ((45, 60, 24), (69, 48, 48), (57, 36, 24)):
+        fmin = 440.0 * 2 ** ((fmin_midi - 69) / 12)
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        inc2, len2 = audio.cqt_table(sr, fmin, n_bins, bpo)
+        assert np.array_equal(inc, inc2) and np.array_equal(length, len2)
+        table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        src = np.stack([ocqt.slice_C_frames(79, 10, 13, 8), ocqt.slice_C_frames(79, 30, 50, 8),
+                        ocqt.slice_C_frames(79, 70, 70, 8)]).astype(np.int32)
+        out = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src).cuda(), table,
+                               n_bins, hop).cpu().numpy()
+        for i in range(3):
+            ref = ocqt.cqt_frames(wave[i], src[i], inc, length, hop)
+            assert np.abs(out[i] - ref).max() <= REL * max(ref.max(), 1e-6), (fmin_midi, i)
+        assert np.all(out[2] == 0)                      # empty slice -> zero columns (t == 0)
+
+
+@pytest.mark.parametrize('case', [
+    dict(shape=(12, 10), k=(4, 2), pool=(2, 2), L=5, pf=2, ef=2, r=2, K=1),
+    dict(shape=(9, 33), k=(4, 16), pool=(2, 8), L=4, pf=2, ef=2, r=2, K=7),
+    dict(shape=(16, 8), k=(2, 2), pool=(2, 2), L=6, pf=3, ef=3, r=2, K=1),
+    dict(shape=(20, 70), k=(4, 16), pool=(2, 8), L=3, pf=0, ef=0, r=0, K=3),
+    dict(shape=(11, 9), k=(4, 2), pool=(2, 2), L=4, pf=4, ef=2, r=1, K=1),
+])
+def test_small_topologies(env, case):
+    """Shallow nets: every layer kind (Cin=1 conv, 32/64/128-channel MFMA convs,
+    identity and projected shortcuts, pooling, dense, both output activations) is
+    visible at the output, unlike in the 33-layer heads."""
+    net = env['rdcnn'].res_net(input_shapes=[case['shape'] + (1,)], output_classes=case['K'],
+                               output_range=[3, 40], kernel_sizes=[case['k']],
+                               pool_sizes=[case['pool']], convolutional_layer_count=case['L'],
+                               feature_expand_frequency=case['ef'],
+                               pool_layer_frequency=case['pf'],
+                               residual_layer_frequencies=case['r'], weight_seed=77)
+    _check_head(env, net, net.cfg, 6, 11)
