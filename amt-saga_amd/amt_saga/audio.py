@@ -19,6 +19,11 @@ from .device import empty, ptr, require_gpu, stream_ptr, to_dev, zeros
 _PLANS = {}
 
 
+def _stride0(t):
+    """Elements between consecutive items of dim 0 (size-1 dims may carry stride 0)."""
+    return t.stride(0) if t.shape[0] > 1 else max(t[0].numel(), 1)
+
+
 def _plan(n_fft, hop, center):
     key = (int(n_fft), int(hop), bool(center), torch.cuda.current_device())
     if key not in _PLANS:
@@ -110,7 +115,7 @@ class AudioBatch:
         self.ph = empty((B, T, ldf, 2)) if with_phase else None
         self.ref_max = empty((B,))
         _lib.check(self.lib.amt_stft_mag(
-            self.plan, ptr(self.wave), B, int(self.L), self.wave.stride(0), ptr(self.mag),
+            self.plan, ptr(self.wave), B, int(self.L), _stride0(self.wave), ptr(self.mag),
             ptr(self.ph), ptr(self.ref_max), T, ldf, T * ldf, stream_ptr()))
         return self
 
@@ -154,7 +159,7 @@ class AudioBatch:
         a.offset_frames = offset_frames.data_ptr() if offset_frames is not None else None
         a.new_max = new_max.data_ptr()
         a.resid_stride = T * self.ldf
-        a.guess_stride = guess_mag.stride(0)
+        a.guess_stride = _stride0(guess_mag)
         a.B, a.T, a.ldf, a.F = B, T, self.ldf, self.F
         a.normalize = int(bool(normalize))
         a.relu = int(bool(relu))
@@ -205,7 +210,7 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     a.length = table[1].data_ptr()
     a.ref = ref.data_ptr() if ref is not None else None
     a.out = out.data_ptr()
-    a.wave_stride = wave.stride(0)
+    a.wave_stride = _stride0(wave)
     a.B, a.L, a.hop, a.frames, a.n_bins, a.n_table = B, L, int(hop), frames, int(n_bins), \
         int(table[0].shape[0])
     _lib.check(lib.amt_cqt_slices(C.byref(a), stream_ptr()))

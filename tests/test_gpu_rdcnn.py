@@ -150,7 +150,7 @@ def test_cqt_slices(env):
 
 @pytest.mark.parametrize('case', [
     dict(shape=(12, 10), k=(4, 2), pool=(2, 2), L=5, pf=2, ef=2, r=2, K=1),
-    dict(shape=(9, 33), k=(4, 16), pool=(2, 8), L=4, pf=2, ef=2, r=2, K=7),
+    dict(shape=(9, 70), k=(4, 16), pool=(2, 8), L=4, pf=2, ef=2, r=2, K=7),
     dict(shape=(16, 8), k=(2, 2), pool=(2, 2), L=6, pf=3, ef=3, r=2, K=1),
     dict(shape=(20, 70), k=(4, 16), pool=(2, 8), L=3, pf=0, ef=0, r=0, K=3),
     dict(shape=(11, 9), k=(4, 2), pool=(2, 2), L=4, pf=4, ef=2, r=1, K=1),

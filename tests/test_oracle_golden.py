@@ -1,0 +1,204 @@
+"""CPU: pin the oracle (and the product's host-side logic) against vectors
+emitted by the reference's own code (tests/golden/reference_vectors.npz) and the
+reference's recorded librosa outputs (tests/golden/subtraction_demo_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import audio as oa
+from oracle import params as op
+
+
+def _fields(p, names):
+    return np.array([float(getattr(p, str(f))) for f in names])
+
+
+SHAPES = ['kernel_size_timing', 'pool_size_timing', 'kernel_size_pitch', 'pool_size_pitch',
+          'kernel_size_instrument', 'pool_size_instrument', 'kernel_size_velocity',
+          'pool_size_velocity', 'residual_layer_frequencies']
+
+
+@pytest.mark.parametrize('tag,kw', [('hp4096', {}), ('hp2048', {'N': 2048}),
+                                    ('hp2048_b2', {'N': 2048, 'bins_per_tone': 2})])
+def test_hyperparams(refvec, tag, kw):
+    from amt_saga.hyperparams import Hyperparams
+    names = refvec['hp_field_names']
+    for p in (op.HyperparamsOracle(**kw), Hyperparams('data', 'sf', **kw)):
+        assert np.array_equal(_fields(p, names), refvec[tag + '_fields'])
+        for s in SHAPES:
+            assert np.array_equal(np.array(getattr(p, s), dtype=np.int64), refvec[tag + '_' + s]), s
+
+
+def test_check_shape_and_list_to_nd_array(refvec):
+    from amt_saga import hyperparams as hp
+    specs = [a for a in refvec['l2nd_in']]
+    labels = list(refvec['l2nd_labels'])
+    dual = [(specs[i], specs[(i + 1) % 5]) for i in range(3)]
+    for mod in (op, hp):
+        x, y = mod.list_to_nd_array(specs, labels)
+        assert x.dtype == np.float64 and np.array_equal(x, refvec['l2nd_x'])
+        assert np.array_equal(y, refvec['l2nd_y'])
+        xd, yd = mod.list_to_nd_array(dual, labels[:3])
+        assert np.array_equal(xd[0], refvec['l2nd_dual_x0'])
+        assert np.array_equal(xd[1], refvec['l2nd_dual_x1'])
+        assert np.array_equal(yd, refvec['l2nd_dual_y'])
+        x1, y1 = mod.list_to_nd_array(specs[0], np.array([60.0]))
+        assert np.array_equal(x1, refvec['l2nd_single_x'])
+        assert np.array_equal(y1, refvec['l2nd_single_y'])
+        ok = []
+        for spec, b, f in ((specs, 174, 8), (specs[0], 174, 8), (dual, 174, 8),
+                           (specs, 348, 8), (specs[0], 174, 9), (tuple(specs), 174, 8)):
+            try:
+                mod.check_shape(spec, b, f)
+                ok.append(1)
+            except ValueError as e:
+                ok.append(0)
+                msg = str(e)
+        assert np.array_equal(ok, refvec['check_shape_ok'])
+        assert msg == str(refvec['check_shape_msg'])
+
+
+def _mk(n_fft, mag, ph=None):
+    T = mag.shape[1]
+    ac = oa.AudioCompleteOracle(np.zeros((n_fft // 4) * (T - 1), dtype=np.float32), n_fft)
+    ac._mag = mag.copy()
+    if ph is not None:
+        ac._ph = ph.copy()
+    return ac
+
+
+def test_subtract_vectors(refvec):
+    n = int(refvec['sub_cases'])
+    assert n == 20
+    for c in range(n):
+        n_fft, off_s, acomp, norm, relu, overkill = refvec['sub%d_args' % c]
+        ac = _mk(int(n_fft), refvec['sub%d_mix' % c], np.ones_like(refvec['sub%d_mix' % c], dtype=np.complex64))
+        g = _mk(int(n_fft), refvec['sub%d_guess' % c])
+        ac.subtract(g, offset=float(off_s), attack_compensation=int(acomp), normalize=bool(norm),
+                    relu=bool(relu), overkill_factor=float(overkill))
+        assert ac._mag.dtype == np.float32
+        assert np.array_equal(ac._mag, refvec['sub%d_out' % c]), c
+        state = [ac._wf is None, ac._F is None, ac._ph is not None, ac._ref_mag is None, ac._D is None]
+        assert np.array_equal(np.array(state, dtype=np.int64), refvec['sub%d_state' % c])
+    ac = _mk(2048, refvec['subraw_mix'])
+    ac.subtract(refvec['subraw_guess'].copy(), offset=0.05)
+    assert np.array_equal(ac._mag, refvec['subraw_out'])
+    assert int(refvec['sub_overrun_raises']) == 1
+    with pytest.raises(ValueError):
+        _mk(256, np.ones((129, 40), np.float32)).subtract(_mk(256, np.ones((129, 13), np.float32)), offset=10.0)
+
+
+def test_frame_maps_and_tone_bins(refvec):
+    from amt_saga import audio as pa
+    for n_fft, T in ((2048, 516), (4096, 258), (4096, 130)):
+        ac = _mk(n_fft, np.zeros((n_fft // 2 + 1, T), np.float32))
+        tag = '%d_%d' % (n_fft, T)
+        assert np.array_equal([ac._seconds_to_frames(t) for t in refvec['s2f_' + tag + '_t']],
+                              refvec['s2f_' + tag])
+        assert np.allclose([ac._frames_to_seconds(f) for f in refvec['f2s_' + tag + '_f']],
+                           refvec['f2s_' + tag], rtol=0, atol=0)
+        assert np.array_equal([ac.midi_tone_to_FFT(m) for m in range(128)], refvec['tone2fft_%d' % n_fft])
+        # product host logic (no GPU needed for the index maps)
+        pc = pa.audio_complete(np.zeros((n_fft // 4) * (T - 1), dtype=np.float32), n_fft)
+        pc._mag = np.zeros((n_fft // 2 + 1, T), np.float32)
+        assert np.array_equal([pc._seconds_to_frames(t) for t in refvec['s2f_' + tag + '_t']],
+                              refvec['s2f_' + tag])
+        assert np.array_equal([pc.midi_tone_to_FFT(m) for m in range(128)], refvec['tone2fft_%d' % n_fft])
+    assert refvec['tone2fft_2048'][60] == 11 and refvec['tone2fft_4096'][60] == 23
+
+
+def test_resize_vectors(refvec):
+    from amt_saga import audio as pa
+    P = refvec['resize_P']
+    for target in (8, 20):
+        for t in (0, 1, 2, 3, 4, 5, 7, 8, 9, 19, 20, 21, 24):
+            exp = refvec['resize_%d_%d' % (t, target)]
+            got = oa.AudioCompleteOracle._resize(P[:, :t], target)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (t, target)
+            # the product's index-map form of the same rule
+            idx = pa.resize_source_frames(t, target)
+            got2 = np.where(idx[None, :] >= 0, P[:, np.maximum(idx, 0)], 0) if t else np.zeros((6, target))
+            assert np.array_equal(got2, exp), (t, target)
+            assert np.array_equal(oa.resize_index_map(t, target), idx)
+            assert np.array_equal(pa.audio_complete._resize(P[:, :t], target), exp)
+
+
+def test_compress_bands_vectors(refvec):
+    from amt_saga import audio as pa
+    for Fb in (1025, 2049):
+        got = oa.AudioCompleteOracle.compress_bands(refvec['cb_in_%d' % Fb], bands=20)
+        assert np.allclose(got, refvec['cb_out_%d' % Fb], rtol=2e-6, atol=0)
+        assert np.array_equal(oa.band_edges(Fb, 20), pa.band_edges(Fb, 20))
+    # SURVEY 8a row a13
+    assert list(oa.band_edges(1025, 20)) == [0, 1, 2, 3, 4, 5, 8, 11, 16, 22, 32, 45, 64, 90, 128,
+                                             181, 256, 362, 512, 724, 1025]
+    assert list(oa.band_edges(2049, 20)) == [0, 1, 2, 3, 4, 6, 9, 14, 21, 30, 45, 66, 97, 142, 208,
+                                             304, 445, 652, 955, 1399, 2049]
+    got = oa.AudioCompleteOracle.compress_bands(refvec['cb_lin_in'], bands=8, log=False)
+    assert np.allclose(got, refvec['cb_lin_out'], rtol=2e-6)
+
+
+def test_section_slice_concat_resize_vectors(refvec):
+    ac = _mk(512, refvec['sec_mag'], refvec['sec_ph'])
+    sec = ac.section(0.2, None, 50)
+    assert np.array_equal(sec._mag, refvec['sec_out_mag'])
+    assert np.array_equal(sec._ph, refvec['sec_out_ph'])
+    assert len(sec._wf) == int(refvec['sec_out_wf_len'])
+    sec2 = ac.section(0.1, 0.4)
+    assert np.array_equal(sec2._mag, refvec['sec2_out_mag'])
+    assert len(sec2._wf) == int(refvec['sec2_out_wf_len'])
+    ac2 = ac.clone()
+    ac2.slice(10, 40)
+    assert np.array_equal(ac2._mag, refvec['slice_out_mag'])
+    assert len(ac2._wf) == int(refvec['slice_out_wf_len'])
+    ac2.concat(sec2)
+    assert np.array_equal(ac2._mag, refvec['concat_out_mag'])
+    assert len(ac2._wf) == int(refvec['concat_out_wf_len'])
+    lo = int(refvec['secpow_lo'])
+    for i in range(4):
+        start, dur = refvec['rsz%d_args' % i]
+        rs = ac.resize(float(start), float(dur), 8, attribs=['mag', 'ph'])
+        assert np.array_equal(rs._mag, refvec['rsz%d_mag' % i])
+        assert np.array_equal(rs._ph, refvec['rsz%d_ph' % i])
+        assert np.array_equal(rs.section_power('mag', lo, lo + 348), refvec['rsz%d_secpow' % i])
+        assert np.array_equal(rs.section_power('mag', 200, 548), refvec['rsz%d_secpow_hi' % i])
+
+
+@pytest.mark.parametrize('name', ['piano', 'strings-piano', 'overdriven'])
+def test_flac_triples_pin_stft_subtract_istft(golden_dir, name):
+    """The reference's recorded outputs (librosa.stft -> magphase -> subtract ->
+    librosa.istft -> PCM-24) are reproduced by the oracle to two LSBs."""
+    z = np.load(os.path.join(golden_dir, 'subtraction_demo_%s.npz' % name))
+    sc = 1.0 / (1 << 23)
+    mix, guess, sub = z['mix'] * sc, z['guess'] * sc, z['sub'] * sc
+    a = oa.AudioCompleteOracle(mix, int(z['n_fft']))
+    g = oa.AudioCompleteOracle(guess, int(z['n_fft']))
+    assert a.shape == (2049, 130)
+    a.subtract(g, offset=float(z['offset_s']), attack_compensation=int(z['attack_compensation']),
+               normalize=bool(z['normalize']))
+    y = a.wf
+    assert y.shape == sub.shape == (132096,)
+    m = np.abs(sub) < 0.999
+    assert np.abs(y - sub)[m].max() <= 3 * sc
+
+
+def test_stft_known_answers():
+    """Analytic KATs: bin-centred tone, impulse, COLA round trip."""
+    n_fft, hop, sr = 2048, 512, 44100
+    k0 = 100
+    t = np.arange(hop * 40)
+    y = 0.7 * np.cos(2 * np.pi * k0 * t / n_fft)
+    F = oa.stft(y, n_fft)
+    assert F.shape == (1025, 41) and F.dtype == np.complex64
+    mid = np.abs(F[:, 20])
+    assert abs(mid[k0] - 0.7 * n_fft / 4) < 1e-3 * n_fft        # Hann coherent gain N/2 * A/2
+    assert abs(mid[k0 - 1] - 0.7 * n_fft / 8) < 1e-3 * n_fft
+    assert mid[k0 + 3:].max() < 1e-3
+    yr = oa.istft(F, hop)
+    assert yr.shape == (hop * 40,) and np.abs(yr - y).max() < 1e-5
+    m, p = oa.magphase(np.array([[0j, 3 + 4j]], dtype=np.complex64))
+    assert m[0, 0] == 0 and p[0, 0] == 1 and abs(m[0, 1] - 5) < 1e-6 and abs(p[0, 1] - (0.6 + 0.8j)) < 1e-6
+    D = oa.amplitude_to_db(np.array([[1.0, 0.1, 1e-9]]), ref=1.0)
+    assert np.allclose(D, [[0, -20, -80]])
+    assert np.allclose(oa.db_to_amplitude(D, 2.0), [[2.0, 0.2, 2e-4]])
