@@ -65,12 +65,21 @@ PROTOTYPES = {
     'amt_short_window': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                    vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]),
     'amt_cqt_slices': (C.c_int, [C.POINTER(CqtArgs), vp]),
+    'amt_round_clamp': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'amt_argmax_rows': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    'amt_resize_table': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'amt_note_select': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, vp, vp, vp]),
+    'amt_pack_events': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    'amt_affine_i32': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'amt_rdcnn_create': (C.c_int, [C.POINTER(vp), C.POINTER(RdcnnDesc), vp, C.c_size_t]),
     'amt_rdcnn_destroy': (C.c_int, [vp]),
     'amt_rdcnn_param_count': (C.c_size_t, [C.POINTER(RdcnnDesc)]),
     'amt_rdcnn_workspace_bytes': (C.c_size_t, [vp, C.c_int]),
     'amt_rdcnn_forward': (C.c_int, [vp, C.POINTER(vp), C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'amt_rdcnn_flops_per_window': (C.c_double, [vp]),
+    'amt_rdcnn_profile': (C.c_int, [vp, C.c_int]),
+    'amt_rdcnn_profile_read': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, c_int32_p, C.c_int]),
 }
 
 _lib = None

@@ -1,0 +1,211 @@
+"""The detect -> subtract loop for B windows at once, device resident.
+
+The reference has no inference loop (main.py only trains); what it
+has is the per-note generator loop of training.py:296-449 that builds the head
+inputs from the residual window and subtracts the *gold* note.  This driver
+composes the same steps with the *predicted* note, for B independent windows
+per launch:
+
+  per iteration (one note per window):
+    C_timing  = compress_bands(mag, 20) / ref_mag_song        training.py:333-336
+    onset,end = rint(timing_start(C_timing)), rint(timing_end(C_timing))
+    wf        = istft(mag * ph)                               util_audio.py:94-97 (what slice_C reads)
+    C_sw_pitch = slice_C(onset, dur, 8, bpt=2) / ref_C_1      training.py:340-342
+    pitch     = rint(pitch_classifier(C_sw_pitch))
+    C_sw_inst = slice_C(onset, dur, 8, bpt=4) / ref_C_inst    training.py:343-346
+    program   = argmax(InstrumentClassifier(C_sw_inst))
+    C_velocity = slice_C(..., bpt=2, nbins=36, lowest=pitch-10) / ref_C_foc   training.py:382-388
+    velocity  = rint(VelocityClassifier(C_velocity))
+    guess     = template bank[(program group, pitch)]         stand-in for render(), synth.py
+    mag       = relu(mag - guess * ref_mag/ref_mag(guess)) at frame `onset`   training.py:449
+
+Everything numeric is a HIP kernel behind the C ABI; torch only holds the
+buffers.  Song-level constants (ref_mag_song, ref_C_*) are computed once in
+prepare(), as the reference computes them once per song (training.py:269-282).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .audio import AudioBatch, cqt_slices, cqt_table, midi_to_hz
+from .device import empty, ptr, require_gpu, stream_ptr, to_dev, zeros
+from .heads import (InstrumentClassifier, VelocityClassifier, pitch_classifier,
+                    timming_classifier)
+
+EVENT_FIELDS = ('window', 'iter', 'pitch', 'program', 'velocity', 'onset_frame', 'end_frame')
+
+
+class TranscriptionLoop:
+    def __init__(self, params, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True,
+                 groups=(0,), ref_frames=8, seeds=None):
+        self.p = params
+        self.heads = tuple(heads)
+        self.iters = int(iters)
+        self.do_subtract = bool(subtract)
+        self.groups = tuple(groups)
+        self.ref_frames = int(ref_frames)
+        self.lib = _lib.load()
+        seeds = seeds or {}
+        self.nets = {}
+        if 'timing' in self.heads:
+            self.nets['timing_start'] = timming_classifier(params, weight_seed=seeds.get('timing_start', 104))
+            self.nets['timing_end'] = timming_classifier(params, weight_seed=seeds.get('timing_end', 105))
+        if 'pitch' in self.heads:
+            self.nets['pitch'] = pitch_classifier(params, weight_seed=seeds.get('pitch', 101))
+        if 'instrument' in self.heads:
+            self.nets['instrument'] = InstrumentClassifier(params, 'instrument',
+                                                           weight_seed=seeds.get('instrument', 102))
+        if 'velocity' in self.heads:
+            self.nets['velocity'] = VelocityClassifier(params, weight_seed=seeds.get('velocity', 103))
+        self._dev_ready = False
+
+    # ---- one-time device setup (not timed: weights / tables / bank upload) ---------
+    def setup_device(self, bank_waves=None):
+        p = self.p
+        dev = require_gpu()
+        sr, lo = p.sr, p.pitch_low
+        f_lo = float(midi_to_hz(lo))
+        self.tab_pitch = cqt_table(sr, f_lo, p.pitch_bands, 12 * p.pitch_bins_per_tone, dev)
+        self.tab_inst = cqt_table(sr, f_lo, p.instrument_bands, 12 * p.instrument_bins_per_tone, dev)
+        # velocity: 36 bins at 2 bins/semitone from (pitch-10) -> one global grid from midi lo-10
+        self.vel_bpt = 2
+        n_vel = self.vel_bpt * (p.pitch_high - lo) + p.bins_velocity
+        self.tab_vel = cqt_table(sr, float(midi_to_hz(lo - 10)), n_vel, 12 * self.vel_bpt, dev)
+        # song-level normaliser grids (training.py:271-282): bpt 1, inst_bpt, 4*inst_bpt over A0..C8
+        span = p.pitch_high - lo
+        self.tab_ref1 = cqt_table(sr, f_lo, span * 1, 12, dev)
+        self.tab_refi = cqt_table(sr, f_lo, span * p.instrument_bins_per_tone,
+                                  12 * p.instrument_bins_per_tone, dev)
+        self.tab_reff = cqt_table(sr, f_lo, span * p.instrument_bins_per_tone * 4,
+                                  12 * p.instrument_bins_per_tone * 4, dev)
+        # index of a program group inside this loop's bank
+        remap = np.zeros(3, dtype=np.int32)
+        for i, g in enumerate(self.groups):
+            remap[g] = i
+        self.prog_group = to_dev(remap[synth.prog_group_table(p.instrument_classes)], torch.int32)
+        if bank_waves is None:
+            bank_waves = synth.guess_bank_waves(self.groups, p.pitch_low, p.pitch_high, sr=sr, device=dev)
+        bank = AudioBatch(bank_waves, p.N, p.H).stft(with_phase=False)
+        self.bank_mag, self.bank_max, self.bank_frames = bank.mag, bank.ref_max, bank.T
+        self.tail_frames = int(synth.TAIL_SECONDS * sr / p.H)
+        for n in self.nets.values():
+            n._ensure()
+        self._dev_ready = True
+        return self
+
+    # ---- small wrappers over the glue kernels -----------------------------------------
+    def _round(self, y, lo, hi):
+        out = empty((y.shape[0],), torch.int32)
+        _lib.check(self.lib.amt_round_clamp(ptr(y), y.shape[0], y.stride(0) if y.dim() > 1 else 1,
+                                            int(lo), int(hi), ptr(out), stream_ptr()))
+        return out
+
+    def _argmax(self, pr):
+        out = empty((pr.shape[0],), torch.int32)
+        _lib.check(self.lib.amt_argmax_rows(ptr(pr), pr.shape[0], pr.shape[1], ptr(out), stream_ptr()))
+        return out
+
+    def _resize_table(self, s, e, T, frames):
+        out = empty((s.shape[0], frames), torch.int32)
+        _lib.check(self.lib.amt_resize_table(ptr(s), ptr(e), s.shape[0], int(T), int(frames), ptr(out),
+                                             stream_ptr()))
+        return out
+
+    def _cqt_max(self, wave, table, n_bins, T):
+        """max over a frame subset of the window's CQT (song-level ref_C_*)."""
+        B = wave.shape[0]
+        nf = min(self.ref_frames, T)
+        frames = np.unique(np.linspace(0, T - 1, nf).round().astype(np.int32))
+        best = None
+        for c0 in range(0, len(frames), 8):
+            cols = frames[c0:c0 + 8]
+            if len(cols) < 8:
+                cols = np.concatenate([cols, np.full(8 - len(cols), -1, np.int32)])
+            src = to_dev(np.tile(cols[None], (B, 1)), torch.int32)
+            o = cqt_slices(wave, src, table, n_bins, self.p.H)
+            m = empty((B,))
+            _lib.check(self.lib.amt_window_max(ptr(o), B, n_bins, 8, n_bins * 8, ptr(m), stream_ptr()))
+            best = m if best is None else torch.maximum(best, m)
+        return best
+
+    # ---- per batch ------------------------------------------------------------------------
+    def prepare(self, wave, refs=None):
+        """STFT of the windows + the song-level constants.  `refs` may supply
+        dict(ref_mag, ref_C_1, ref_C_inst, ref_C_foc) tensors [B]."""
+        if not self._dev_ready:
+            self.setup_device()
+        p = self.p
+        b = AudioBatch(wave, p.N, p.H).stft(with_phase=True)
+        refs = dict(refs or {})
+        if 'ref_mag' not in refs:
+            refs['ref_mag'] = b.ref_max.clone()
+        need_cqt = any(h in self.heads for h in ('pitch', 'instrument', 'velocity'))
+        if need_cqt:
+            if 'pitch' in self.heads and 'ref_C_1' not in refs:
+                refs['ref_C_1'] = self._cqt_max(b.wave, self.tab_ref1, self.tab_ref1[0].shape[0], b.T)
+            if 'instrument' in self.heads and 'ref_C_inst' not in refs:
+                refs['ref_C_inst'] = self._cqt_max(b.wave, self.tab_refi, self.tab_refi[0].shape[0], b.T)
+            if 'velocity' in self.heads and 'ref_C_foc' not in refs:
+                refs['ref_C_foc'] = self._cqt_max(b.wave, self.tab_reff, self.tab_reff[0].shape[0], b.T)
+        self.refs = refs
+        return b
+
+    def iterate(self, b, it, events, window0=0):
+        p = self.p
+        B, T = b.mag.shape[0], b.mag.shape[1]
+        st = stream_ptr()
+        onset = end = pitch = program = velocity = None
+        if 'timing' in self.heads:
+            ct = b.compress_bands(p.timing_bands, self.refs['ref_mag'], p.timing_frames)
+            ts = self.nets['timing_start'].classify(ct)
+            te = self.nets['timing_end'].classify(ct)
+            onset = self._round(ts, 0, T - 1)
+            end = self._round(te, 0, T)
+        else:
+            onset = zeros((B,), torch.int32)
+            end = torch.full((B,), p.pitch_frames, dtype=torch.int32, device=onset.device)
+        src = self._resize_table(onset, end, T, p.pitch_frames)
+        need_wave = any(h in self.heads for h in ('pitch', 'instrument', 'velocity'))
+        wave_r = b.wave if (it == 0 and b.wave is not None and b.wave.shape[1] == p.H * (T - 1)) \
+            else None
+        if need_wave and wave_r is None:
+            wave_r = b.istft()
+        if 'pitch' in self.heads:
+            cp = cqt_slices(wave_r, src, self.tab_pitch, p.pitch_bands, p.H, ref=self.refs['ref_C_1'])
+            pitch = self._round(self.nets['pitch'].classify(cp), p.pitch_low, p.pitch_high)
+        else:
+            pitch = torch.full((B,), 60, dtype=torch.int32, device=onset.device)
+        if 'instrument' in self.heads:
+            ci = cqt_slices(wave_r, src, self.tab_inst, p.instrument_bands, p.H, ref=self.refs['ref_C_inst'])
+            program = self._argmax(self.nets['instrument'].classify(ci))
+        if 'velocity' in self.heads:
+            bin0 = empty((B,), torch.int32)
+            _lib.check(self.lib.amt_affine_i32(ptr(pitch), B, self.vel_bpt, -self.vel_bpt * p.pitch_low,
+                                               ptr(bin0), st))
+            cv = cqt_slices(wave_r, src, self.tab_vel, p.bins_velocity, p.H, bin0=bin0,
+                            ref=self.refs['ref_C_foc'])
+            velocity = self._round(self.nets['velocity'].classify(cv), 1, 127)
+        if self.do_subtract:
+            gidx = empty((B,), torch.int32)
+            gfr = empty((B,), torch.int32)
+            _lib.check(self.lib.amt_note_select(
+                ptr(program), ptr(pitch), ptr(onset), ptr(end), ptr(self.prog_group),
+                self.prog_group.shape[0], B, p.pitch_low, p.pitch_high - p.pitch_low + 1,
+                self.tail_frames, self.bank_frames, ptr(gidx), ptr(gfr), st))
+            b.subtract(self.bank_mag, self.bank_max, gidx, gfr, onset, normalize=True, relu=True)
+        _lib.check(self.lib.amt_pack_events(B, int(window0), int(it), ptr(pitch), ptr(program),
+                                            ptr(velocity), ptr(onset), ptr(end), ptr(events[it]), st))
+
+    def run(self, wave, window0=0, refs=None):
+        """All iterations for one batch.  Returns (events [iters, B, 7] int32 device,
+        the AudioBatch holding the residual)."""
+        b = self.prepare(wave, refs)
+        events = empty((self.iters, b.mag.shape[0], len(EVENT_FIELDS)), torch.int32)
+        for it in range(self.iters):
+            self.iterate(b, it, events, window0)
+        return events, b
+
+    def flops_per_window_iter(self):
+        return sum(n.flops_per_window for n in self.nets.values())

@@ -249,6 +249,26 @@ class res_net:
         self._ensure()
         return float(self._lib.amt_rdcnn_flops_per_window(self._net))
 
+    # ---- measurement hook ------------------------------------------------------------
+    def profile(self, enable=True):
+        self._ensure()
+        _lib.check(self._lib.amt_rdcnn_profile(self._net, int(bool(enable))))
+
+    def profile_read(self, reset=True):
+        """[{tower, layer, kh, kw, cin, cout, H, W, ms, windows, flops_per_window}] per conv layer."""
+        self._ensure()
+        n = C.c_int32(0)
+        _lib.check(self._lib.amt_rdcnn_profile_read(self._net, None, None, None, None, 0, C.byref(n), 0))
+        cap = n.value
+        desc = np.zeros((cap, 8), np.int32)
+        ms = np.zeros(cap); win = np.zeros(cap); fl = np.zeros(cap)
+        _lib.check(self._lib.amt_rdcnn_profile_read(
+            self._net, desc.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p),
+            win.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), cap, C.byref(n), int(bool(reset))))
+        keys = ('tower', 'layer', 'kh', 'kw', 'cin', 'cout', 'H', 'W')
+        return [dict(zip(keys, map(int, desc[r])), ms=float(ms[r]), windows=float(win[r]),
+                     flops_per_window=float(fl[r])) for r in range(cap)]
+
     # ---- forward ---------------------------------------------------------------
     def predict_device(self, xs, return_logits=False):
         """xs: list (one per tower) of device tensors [B, H, W] f32 (NHWC, C=1).

@@ -1,0 +1,114 @@
+"""Deterministic additive synthesiser: the stand-in for note_sequence.render()
+(fluidsynth + GM soundfont, /root/reference/util_audio.py:758-786), neither of
+which exists here (SURVEY 7 hard part 3, 8d).  It produces (a) the synthetic
+benchmark windows and (b) the guess-template bank the subtraction step reads.
+
+    note(g, p, v, t0, d) = env_g(t - t0; d) * sum_{h=1..H_g} a_{g,h} sin(2 pi h f_p (t - t0))
+    f_p = 440 * 2**((p-69)/12); harmonics above Nyquist are dropped
+    presets: piano   H=12, a_h = h**-1.5, exp decay tau = 0.6 s
+             strings H=16, a_h = h**-1.0, 80 ms linear attack, sustain
+             guitar  H=10, a_h = h**-1.2, exp decay tau = 0.35 s
+    every note is followed by a release (exp, 60 ms) inside a 1 s tail (:876)
+    window scaling follows render() (:778-781):
+        wf * (vel_max/128)**4 / max|wf|,  vel_max - 12 for a single note
+
+Input generation only -- not part of the timed hot path.  Runs in torch on the
+device it is given (CPU for tests, the GPU for the benchmark) with float64
+phase so both give the same samples to ~1e-7.
+"""
+import numpy as np
+import torch
+
+PRESETS = {
+    'piano': dict(H=12, slope=1.5, tau=0.6, attack=0.002, sustain=False),
+    'strings': dict(H=16, slope=1.0, tau=None, attack=0.08, sustain=True),
+    'guitar': dict(H=10, slope=1.2, tau=0.35, attack=0.002, sustain=False),
+}
+PROGRAM_GROUPS = ['piano', 'strings', 'guitar']
+RELEASE_TAU = 0.06
+TAIL_SECONDS = 1.0
+
+
+def program_to_group(program):
+    """GM program number -> preset index: 24-31 guitars, 40-55 strings/ensemble,
+    everything else piano."""
+    if 24 <= program <= 31:
+        return 2
+    if 40 <= program <= 55:
+        return 1
+    return 0
+
+
+def prog_group_table(n_prog=112):
+    return np.array([program_to_group(p) for p in range(n_prog)], dtype=np.int32)
+
+
+def _note(t, group, pitch, onset, dur, sr):
+    """t: [L] float64 tensor of seconds; returns float64 [L]."""
+    pr = PRESETS[PROGRAM_GROUPS[group]]
+    f0 = 440.0 * 2.0 ** ((pitch - 69) / 12.0)
+    tt = t - onset
+    on = (tt >= 0).to(t.dtype)
+    ttc = torch.clamp(tt, min=0.0)
+    env = torch.clamp(ttc / pr['attack'], max=1.0)
+    if pr['tau'] is not None:
+        env = env * torch.exp(-ttc / pr['tau'])
+    rel = torch.clamp(tt - dur, min=0.0)
+    env = env * torch.exp(-rel / RELEASE_TAU) * on
+    env = env * (tt < dur + TAIL_SECONDS).to(t.dtype)
+    y = torch.zeros_like(t)
+    for h in range(1, pr['H'] + 1):
+        if h * f0 >= sr / 2:
+            break
+        y = y + (h ** -pr['slope']) * torch.sin(2.0 * np.pi * h * f0 * ttc)
+    return y * env
+
+
+def render_window(notes, L, sr=44100, device='cpu'):
+    """notes: list of (group, pitch, velocity, onset_s, dur_s).  float32 [L]."""
+    t = torch.arange(L, dtype=torch.float64, device=device) / sr
+    wf = torch.zeros(L, dtype=torch.float64, device=device)
+    for (g, p, v, t0, d) in notes:
+        amp = (v / 128.0) ** 4          # fluidsynth-like loudness spread between notes
+        wf = wf + amp * _note(t, g, p, t0, d, sr)
+    vel_max = max(n[2] for n in notes)
+    if len(notes) == 1:
+        vel_max = max(1, vel_max - 12)
+    peak = wf.abs().max()
+    if float(peak) > 0:
+        wf = wf * ((vel_max / 128.0) ** 4 / peak)
+    return wf.to(torch.float32)
+
+
+def random_notes(rng, n_notes, groups=(0,), max_onset=3.0):
+    """p ~ U{21..108}, v ~ U{5..125}, t0 ~ U[0,3), d ~ U[0.1,2]."""
+    out = []
+    for _ in range(n_notes):
+        out.append((int(rng.choice(groups)), int(rng.integers(21, 109)), int(rng.integers(5, 126)),
+                    float(rng.uniform(0, max_onset)), float(rng.uniform(0.1, 2.0))))
+    return out
+
+
+def make_windows(B, L, seed, notes_per_window=(3, 3), groups=(0,), sr=44100, device='cpu',
+                 max_onset=3.0):
+    """[B, L] float32 tensor of synthetic windows + the note lists."""
+    rng = np.random.default_rng(seed)
+    waves, notes = [], []
+    for _ in range(B):
+        n = int(rng.integers(notes_per_window[0], notes_per_window[1] + 1))
+        ns = random_notes(rng, n, groups, max_onset)
+        notes.append(ns)
+        waves.append(render_window(ns, L, sr, device))
+    return torch.stack(waves), notes
+
+
+def guess_bank_waves(groups=(0,), pitch_lo=21, pitch_hi=108, dur=1.0, velocity=100, sr=44100,
+                     device='cpu'):
+    """One rendered single-note guess per (group, pitch): [G*n_pitch, L_g] float32,
+    L_g = (dur + 1 s tail) * sr samples (the reference's guess = note + 1 s, :876)."""
+    Lg = int(round((dur + TAIL_SECONDS) * sr))
+    out = []
+    for g in groups:
+        for p in range(pitch_lo, pitch_hi + 1):
+            out.append(render_window([(g, p, velocity, 0.0, dur)], Lg, sr, device))
+    return torch.stack(out)

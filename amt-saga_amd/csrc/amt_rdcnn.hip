@@ -399,7 +399,14 @@ struct Tower {
     size_t max_act = 0;        // floats per window of the largest activation
     int out_h, out_w, out_c;
 };
+struct ProfPending { hipEvent_t e0, e1; int tower, layer, windows; };
+struct ProfAcc { double ms = 0, windows = 0; long launches = 0; };
 struct amt_rdcnn {
+    // optional per-conv-launch timing (HIP events on the caller's stream)
+    mutable bool prof_on = false;
+    mutable std::vector<ProfPending> prof_pending;
+    mutable std::vector<hipEvent_t> prof_free;
+    mutable std::vector<std::vector<ProfAcc>> prof_acc;   // [tower][layer]
     amt_rdcnn_desc d;
     std::vector<Tower> towers;
     std::vector<float *> allocs;
@@ -535,6 +542,8 @@ size_t amt_rdcnn_param_count(const amt_rdcnn_desc *desc) {
 
 int amt_rdcnn_destroy(amt_rdcnn *net) {
     if (!net) return AMT_OK;
+    for (const ProfPending &pp : net->prof_pending) { (void)hipEventDestroy(pp.e0); (void)hipEventDestroy(pp.e1); }
+    for (hipEvent_t e : net->prof_free) (void)hipEventDestroy(e);
     for (float *p : net->allocs) (void)hipFree(p);
     delete net;
     return AMT_OK;
@@ -658,6 +667,49 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
 
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net) { return net ? net->flops : 0.0; }
 
+int amt_rdcnn_profile(amt_rdcnn *net, int enable) {
+    if (!net) return AMT_E_INVALID;
+    net->prof_on = enable != 0;
+    if (net->prof_acc.empty()) {
+        net->prof_acc.resize(net->towers.size());
+        for (size_t t = 0; t < net->towers.size(); ++t) net->prof_acc[t].resize(net->towers[t].convs.size());
+    }
+    return AMT_OK;
+}
+
+int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *windows,
+                           double *flops_per_window, int cap, int *n_rows, int reset) {
+    if (!net || !n_rows) return AMT_E_INVALID;
+    for (const ProfPending &pp : net->prof_pending) {
+        AMT_HIP_CHECK(hipEventSynchronize(pp.e1));
+        float e = 0.f;
+        AMT_HIP_CHECK(hipEventElapsedTime(&e, pp.e0, pp.e1));
+        ProfAcc &a = net->prof_acc[pp.tower][pp.layer];
+        a.ms += e; a.windows += pp.windows; a.launches += 1;
+        net->prof_free.push_back(pp.e0);
+        net->prof_free.push_back(pp.e1);
+    }
+    net->prof_pending.clear();
+    int r = 0;
+    for (size_t t = 0; t < net->prof_acc.size(); ++t)
+        for (size_t i = 0; i < net->prof_acc[t].size(); ++i) {
+            if (r < cap && desc && ms && windows && flops_per_window) {
+                const ConvOp &c = net->towers[t].convs[i];
+                int32_t *d = desc + (size_t)r * 8;
+                d[0] = (int)t; d[1] = (int)i + 1; d[2] = c.kh; d[3] = c.kw; d[4] = c.cin; d[5] = c.cout;
+                d[6] = c.H; d[7] = c.W;
+                ms[r] = net->prof_acc[t][i].ms;
+                windows[r] = net->prof_acc[t][i].windows;
+                flops_per_window[r] = 2.0 * c.H * c.W * (double)c.kh * c.kw * c.cin * c.cout;
+            }
+            ++r;
+        }
+    *n_rows = r;
+    if (reset)
+        for (auto &v : net->prof_acc) for (auto &a : v) a = ProfAcc();
+    return AMT_OK;
+}
+
 #define RD_CHUNK 512
 static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     size_t ma = 0;
@@ -728,6 +780,14 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         sc = p0; sc_stride = p0_stride;
                     }
                 }
+                hipEvent_t pe0 = nullptr, pe1 = nullptr;
+                if (net->prof_on) {
+                    for (hipEvent_t *pe : {&pe0, &pe1}) {
+                        if (!net->prof_free.empty()) { *pe = net->prof_free.back(); net->prof_free.pop_back(); }
+                        else AMT_HIP_CHECK(hipEventCreate(pe));
+                    }
+                    AMT_HIP_CHECK(hipEventRecord(pe0, st));
+                }
                 if (c.cin == 1) {
                     Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                    c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
@@ -744,6 +804,10 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                                   (W + c.TW - 1) / c.TW};
                     const int rc = launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
+                }
+                if (net->prof_on) {
+                    AMT_HIP_CHECK(hipEventRecord(pe1, st));
+                    net->prof_pending.push_back(ProfPending{pe0, pe1, t, i, Bc});
                 }
                 if (c.residual) { p0 = o; p0_stride = o_stride; }
                 cur = o; cur_stride = o_stride;

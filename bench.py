@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the AMT-SAGA hot path on MI355X: audio windows/sec through the
+detect -> subtract loop (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload c3|c2|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic windows that are
+already resident in HBM: STFT(2048) -> mag/phase/max -> `iters` x [features ->
+RDCNN heads -> note decision -> guess lookup -> subtract] -> event gather.
+Weak scaling: every rank processes the same number of windows.
+
+Prints ONE JSON line on rank 0 with the driver contract plus
+  roofline      dominant kernel (timing-head conv, fp32 MFMA): achieved TFLOP/s from
+                HIP events recorded around every conv launch inside the timed region
+  roofline_stft the north-star HBM kernel pair (STFT->mag/phase/max, subtract):
+                algorithmic GB/s from HIP events on the launch stream
+  cpu_baseline  the numpy oracle ("port") timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'amt-saga_amd')]
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    'c2': dict(B=256, heads=('pitch',), iters=1, subtract=False, notes=(1, 1), groups=(0,), seed=2,
+               name='C2: 256 single-note piano windows, STFT(2048) + RDCNN pitch head'),
+    # BASELINE.json configs[2] -- the largest single-GPU config and the first with the full loop
+    'c3': dict(B=1024, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True, notes=(3, 3),
+               groups=(0,), seed=3,
+               name='C3: 1024 polyphonic piano windows, STFT(2048) + pitch+velocity+timing(start,end) '
+                    'heads + 1 subtraction iteration'),
+    # per-GPU shard of BASELINE.json configs[4] (16384 windows / 8 GPUs)
+    'c5': dict(B=2048, heads=('timing', 'pitch', 'instrument', 'velocity'), iters=5, subtract=True,
+               notes=(2, 4), groups=(0, 1, 2), seed=5,
+               name='C5 shard: 2048 mixed-instrument windows per GPU, all heads, 5 iterations'),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense FP32 matrix peak
+
+
+def build(workload, B):
+    from amt_saga.hyperparams import Hyperparams
+    from amt_saga.loop import TranscriptionLoop
+    p = Hyperparams(N=2048)
+    loop = TranscriptionLoop(p, heads=workload['heads'], iters=workload['iters'],
+                             subtract=workload['subtract'], groups=workload['groups'])
+    loop.setup_device()
+    return p, loop
+
+
+def cpu_baseline(p, workload, loop, wave_cpu, refs_cpu, budget_s):
+    """Oracle loop on the host cores: same algorithm, same weights, same inputs."""
+    from oracle.loop import LoopOracle
+    from amt_saga import synth
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    weights = {k: n.weights for k, n in loop.nets.items()}
+    bank = synth.guess_bank_waves(workload['groups'], p.pitch_low, p.pitch_high, sr=p.sr).numpy() \
+        if workload['subtract'] else None
+    remap = np.zeros(3, np.int32)
+    for i, g in enumerate(workload['groups']):
+        remap[g] = i
+    orc = LoopOracle(p, workload['heads'], weights, iters=workload['iters'],
+                     subtract=workload['subtract'],
+                     prog_group=remap[synth.prog_group_table(p.instrument_classes)], bank_waves=bank)
+    done, t_total = 0, 0.0
+    for i in range(wave_cpu.shape[0]):
+        w = wave_cpu[i]
+        refs = {k: v[i] for k, v in refs_cpu.items()}   # song-level constants are inputs (not timed)
+        t0 = time.perf_counter()
+        orc.run_window(w, refs, i)
+        t_total += time.perf_counter() - t0
+        done += 1
+        if t_total > budget_s:
+            break
+    return dict(value=done / t_total, unit='windows/s', cores=int(thr), kind='port',
+                sample='%d window(s) of the same workload, numpy/OpenBLAS oracle (oracle/loop.py), '
+                       '%.1f s of CPU work; host has %d logical cores' % (done, t_total, os.cpu_count() or 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--windows', type=int, default=0, help='windows per GPU (default: the workload size)')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from amt_saga import dist as adist, synth
+    rank, world, local = adist.init()
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU: the HIP path has no CPU fallback')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    wl = WORKLOADS[args.workload]
+    B = args.windows or wl['B']
+    p, loop = build(wl, B)
+    L = p.H * (p.timing_frames - 1)                         # 263,680 samples -> exactly 516 frames
+
+    # synthetic windows, generated on the device (inputs resident in HBM before timing)
+    wave, _ = synth.make_windows(B, L, seed=wl['seed'] * 1000 + rank, notes_per_window=wl['notes'],
+                                 groups=wl['groups'], sr=p.sr, device=dev)
+    window0 = rank * B
+    # song-level constants once per batch (training.py:269-282 computes them once per song)
+    loop.prepare(wave)
+    refs = loop.refs
+    timing_nets = [loop.nets[k] for k in ('timing_start', 'timing_end') if k in loop.nets]
+    prof_nets = timing_nets or list(loop.nets.values())
+
+    def step():
+        ev, b = loop.run(wave, window0=window0, refs=refs)
+        return adist.gather_events(ev.reshape(-1, 7), n_total=B * world * wl['iters']), b
+
+    for _ in range(args.warmup):
+        step()
+    for n in prof_nets:
+        n.profile(True)
+        n.profile_read(reset=True)
+    # STFT / subtract kernel timing with events on the launch stream (torch's current stream)
+    from amt_saga.audio import AudioBatch
+    ev_pairs = []
+    orig_stft, orig_sub = AudioBatch.stft, AudioBatch.subtract
+
+    def timed(fn, tag):
+        def w(self, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(self, *a, **k)
+            e1.record()
+            ev_pairs.append((tag, e0, e1))
+            return r
+        return w
+    AudioBatch.stft, AudioBatch.subtract = timed(orig_stft, 'stft'), timed(orig_sub, 'subtract')
+
+    adist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        events, last = step()
+    torch.cuda.synchronize()
+    adist.barrier()
+    dt = time.perf_counter() - t0
+    AudioBatch.stft, AudioBatch.subtract = orig_stft, orig_sub
+    dt = adist.max_over_ranks(dt)
+    value = B * world * args.steps / dt
+
+    # ---- roofline of the dominant kernel (HIP events around every conv launch) -------------
+    rows = []
+    for n in prof_nets:
+        rows += n.profile_read(reset=True)
+        n.profile(False)
+    by_class = {}
+    for r in rows:
+        key = (r['kh'], r['kw'], r['cin'], r['cout'], r['H'], r['W'])
+        a = by_class.setdefault(key, dict(ms=0.0, flops=0.0, windows=0.0))
+        a['ms'] += r['ms']
+        a['flops'] += r['flops_per_window'] * r['windows']
+        a['windows'] += r['windows']
+    dom_key = max(by_class, key=lambda k: by_class[k]['ms'])
+    dom = by_class[dom_key]
+    conv_ms_total = sum(a['ms'] for a in by_class.values())
+    achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
+                    frac=round(achieved_tf / MFMA_F32_PEAK_TF, 4), traffic=None,
+                    kernel='conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)' % dom_key,
+                    share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
+                    conv_ms_per_step=round(conv_ms_total / args.steps, 2))
+    F, T, ldf = p.N // 2 + 1, p.timing_frames, (p.N // 2 + 1 + 3) & ~3
+    stft_ms = sum(e0.elapsed_time(e1) for tag, e0, e1 in ev_pairs if tag == 'stft')
+    sub_ms = sum(e0.elapsed_time(e1) for tag, e0, e1 in ev_pairs if tag == 'subtract')
+    n_stft = sum(1 for tag, _, _ in ev_pairs if tag == 'stft')
+    n_sub = sum(1 for tag, _, _ in ev_pairs if tag == 'subtract')
+    stft_bytes = B * (4 * L + 4 * F * T + 8 * F * T)                    # wave in, mag + unit phase out
+    sub_bytes = B * (2 * 4 * F * T + 4 * F * loop.bank_frames) if n_sub else 0
+    hbm_ms = stft_ms + sub_ms
+    hbm_gbs = (n_stft * stft_bytes + n_sub * sub_bytes) / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else 0.0
+    roofline_stft = dict(bound='hbm', achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                         frac=round(hbm_gbs / HBM_PEAK_GBS, 4), traffic=None,
+                         kernel='stft_mag_kernel<2048,phase> + subtract_kernel',
+                         stft_gbs=round(n_stft * stft_bytes / (stft_ms * 1e-3) / 1e9, 1) if stft_ms else None,
+                         subtract_gbs=round(n_sub * sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
+                         ms_per_step=round(hbm_ms / args.steps, 3))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        refs_cpu = {k: v[:8].cpu().numpy() for k, v in refs.items()}
+        cpu = cpu_baseline(p, wl, loop, wave[:8].cpu().numpy(), refs_cpu, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            'metric': 'audio windows/sec (44.1 kHz, 2048-pt STFT) through full detect->subtract loop',
+            'value': round(value, 2), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (additive-synth windows, seeded random-init weights)',
+            'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
+                       'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
+                       'parallelism': 'windows sharded x%d, event all-gather' % world},
+            'roofline': roofline, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
+            'events_checksum': int(events.to(torch.int64).sum().item()),
+        }
+        if cpu:
+            out['speedup_vs_cpu_baseline'] = round(value / cpu['value'], 1)
+        print(json.dumps(out), flush=True)
+    adist.shutdown()
+
+
+if __name__ == '__main__':
+    main()

@@ -153,6 +153,37 @@ typedef struct amt_cqt_args {
 int amt_cqt_slices(const amt_cqt_args *args, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * Loop glue: predicted note -> integer decisions, gather tables, guess pick,
+ * event records.  Restates per window what training.py:296-449 does with the
+ * gold note (the reference never rounds: predict returns floats,
+ * RDCNN.py:591-597; the rounding rules are rint / first argmax, as numpy).
+ * ------------------------------------------------------------------------ */
+/* out[i] = clamp(rint(x[i*stride]), lo, hi)  (half-to-even; NaN -> lo) */
+int amt_round_clamp(const float *x, int n, int stride, int lo, int hi, int32_t *out,
+                    void *stream);
+/* out[i] = first argmax of p[i][0..K)  (np.argmax) */
+int amt_argmax_rows(const float *p, int n, int K, int32_t *out, void *stream);
+/* out[b][j] = source frame of column j of _resize(X[:, start[b]:end[b]], frames)
+ * (util_audio.py:384-409 with numpy slice clamping to [0,T]); -1 = zero column */
+int amt_resize_table(const int32_t *start, const int32_t *end, int n, int T, int frames,
+                     int32_t *out, void *stream);
+/* guess_index = prog_group[program]*n_pitch + (pitch-pitch_lo) (clamped);
+ * guess_frames = min(max(end-onset,0) + tail_frames, bank_frames)
+ * (the rendered guess = note + 1 s release, util_audio.py:876).  program /
+ * prog_group may be NULL (=> group 0). */
+int amt_note_select(const int32_t *program, const int32_t *pitch, const int32_t *onset,
+                    const int32_t *end, const int32_t *prog_group, int n_prog, int n,
+                    int pitch_lo, int n_pitch, int tail_frames, int bank_frames,
+                    int32_t *guess_index, int32_t *guess_frames, void *stream);
+/* events[i] = {window0+i, iter, pitch, program, velocity, onset_frame, end_frame}
+ * (int32 x 7); NULL inputs are recorded as -1 */
+int amt_pack_events(int n, int window0, int iter, const int32_t *pitch,
+                    const int32_t *program, const int32_t *velocity, const int32_t *onset,
+                    const int32_t *end, int32_t *events, void *stream);
+/* out[i] = x[i]*mul + add (bin offsets of the focused CQT grids) */
+int amt_affine_i32(const int32_t *x, int n, int mul, int add, int32_t *out, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * RDCNN forward (replaces res_net.predict, RDCNN.py:591-597, for the graph
  * built by RDCNN.py:176-233).
  * ------------------------------------------------------------------------ */
@@ -189,6 +220,15 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B,
                       size_t workspace_bytes, void *stream);
 /* FLOPs (2*MAC) of one window's forward, for roofline accounting */
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net);
+/* Measurement hook: when enabled, every convolution launch of amt_rdcnn_forward
+ * is bracketed by HIP events on the caller's stream.  amt_rdcnn_profile_read
+ * waits for the recorded events and returns one row per conv layer:
+ * desc[r] = {tower, layer, kh, kw, cin, cout, H, W}, ms[r] = summed kernel time,
+ * windows[r] = windows processed, flops_per_window[r] = 2*H*W*kh*kw*cin*cout.
+ * n_rows receives the number of layers (call with cap = 0 to size buffers). */
+int amt_rdcnn_profile(amt_rdcnn *net, int enable);
+int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *windows,
+                           double *flops_per_window, int cap, int *n_rows, int reset);
 
 #ifdef __cplusplus
 }

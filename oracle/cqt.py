@@ -60,26 +60,30 @@ def cqt_table(sr, fmin_hz, n_bins, bins_per_octave):
 
 def cqt_frames(x, frames, phase_inc, length, hop):
     """|C[k, t]| for the listed STFT-frame indices (-1 -> zero column).
-    x float [L]; returns float64 [n_bins, len(frames)]."""
+    x float [L]; returns float64 [n_bins, len(frames)].
+
+    The oscillator phase of absolute sample m is (m * inc mod 2^32) / 2^32 turns.
+    Because that map is additive mod 2^32, exp(-i phi(a+n)) = exp(-i phi(a)) *
+    exp(-i phi(n)) exactly, and the unit factor exp(-i phi(a)) drops out of the
+    magnitude -- so one basis per bin (relative index n) serves every frame."""
     x = np.asarray(x, dtype=np.float64)
     L = len(x)
     out = np.zeros((len(length), len(frames)))
     for k in range(len(length)):
         nk = int(length[k])
         inc = int(phase_inc[k])
-        n = np.arange(nk)
-        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / nk)
+        n = np.arange(nk, dtype=np.uint64)
+        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(nk) / nk)
+        ph = ((n * np.uint64(inc)) & np.uint64(0xFFFFFFFF)).astype(np.float64)
+        basis = w * np.exp(-1j * ph * (2.0 * np.pi / 2.0 ** 32))
         for j, t in enumerate(frames):
             if t < 0:
                 continue
             a = int(t) * hop - nk // 2
-            m = a + n
-            ok = (m >= 0) & (m < L)
-            mm = m[ok]
-            # exact uint32 oscillator phase of the absolute sample index
-            ph = ((mm.astype(np.uint64) * np.uint64(inc)) & np.uint64(0xFFFFFFFF)).astype(np.float64)
-            ang = ph * (2.0 * np.pi / 2.0 ** 32)
-            s = np.sum(x[mm] * w[ok] * np.exp(-1j * ang))
+            lo, hi = max(a, 0), min(a + nk, L)
+            if hi <= lo:
+                continue
+            s = np.dot(x[lo:hi], basis[lo - a:hi - a])
             out[k, j] = np.abs(s) * 2.0 / np.sqrt(nk)
     return out
 
