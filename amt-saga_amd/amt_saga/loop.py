@@ -47,10 +47,12 @@ class TranscriptionLoop:
         self.groups = tuple(groups)
         self.ref_frames = int(ref_frames)
         self.lib = _lib.load()
+        # default seeds: synthetic timing_start / timing_end nets whose (nearly input-independent)
+        # outputs satisfy onset < end, so the short-window features are not empty
         seeds = seeds or {}
         self.nets = {}
         if 'timing' in self.heads:
-            self.nets['timing_start'] = timming_classifier(params, weight_seed=seeds.get('timing_start', 104))
+            self.nets['timing_start'] = timming_classifier(params, weight_seed=seeds.get('timing_start', 107))
             self.nets['timing_end'] = timming_classifier(params, weight_seed=seeds.get('timing_end', 105))
         if 'pitch' in self.heads:
             self.nets['pitch'] = pitch_classifier(params, weight_seed=seeds.get('pitch', 101))
