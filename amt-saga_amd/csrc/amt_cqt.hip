@@ -68,11 +68,12 @@ __global__ __launch_bounds__(256) void cqt_slices_kernel(amt_cqt_args a) {
     for (int m = m_lo + tid; m < m_hi; m += 256) {
         const float xv = x[m];
         const unsigned int ph = (unsigned int)m * inc;                 // exact mod 2^32
-        float s, c;
-        sincospif((float)ph * 4.656612873077393e-10f, &s, &c);          // 2*ph/2^32 half-turns
+        // v_sin_f32 / v_cos_f32 take their argument in turns (1.0 = 2 pi), |x| <= 256
+        const float turns = (float)ph * 2.3283064365386963e-10f;        // ph / 2^32
+        const float s = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
         const float xr = xv * c, xi = -xv * s;                          // x * exp(-i phi)
-        float sw, cw;
-        sincospif(2.0f * (float)(m - a0) * inv_nk, &sw, &cw);
+        const float wt = (float)(m - a0) * inv_nk;
+        const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
 #pragma unroll
         for (int j = 0; j < AMT_CQT_MAXF; ++j) {
             const int n = m - start[j];

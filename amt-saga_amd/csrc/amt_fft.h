@@ -102,13 +102,23 @@ __device__ __forceinline__ void fft_pass(float2 *buf, const float2 *tw, Loader l
         if (NB >= AMT_FFT_THREADS || j < NB) {
             const int k = j & (NS - 1);
             if constexpr (NS > 1) {
+                // one LDS read; w^2..w^(R-1) by multiplication (error <= a few ulp, and no
+                // bank-conflicted strided table walks)
                 constexpr int TSTEP = N / (NS * R);
-#pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    float2 w = tw[r * k * TSTEP];
-                    if (INV) w.y = -w.y;
-                    x[bi][r] = cmul(x[bi][r], w);
+                float2 w1 = tw[k * TSTEP];
+                if (INV) w1.y = -w1.y;
+                float2 wp[R];
+                wp[1] = w1;
+                if constexpr (R > 2) wp[2] = cmul(w1, w1);
+                if constexpr (R > 3) wp[3] = cmul(wp[2], w1);
+                if constexpr (R > 4) {
+                    wp[4] = cmul(wp[2], wp[2]);
+                    wp[5] = cmul(wp[4], w1);
+                    wp[6] = cmul(wp[3], wp[3]);
+                    wp[7] = cmul(wp[4], wp[3]);
                 }
+#pragma unroll
+                for (int r = 1; r < R; ++r) x[bi][r] = cmul(x[bi][r], wp[r]);
             }
             dft_r<R, INV>(x[bi]);
             const int base = (j - k) * R + k;

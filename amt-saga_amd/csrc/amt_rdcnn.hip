@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 }
 
 // ---- first layer (Cin = 1): direct convolution on the VALU ---------------------
-// thread = (position, cout); consecutive threads -> consecutive cout (coalesced
-// NHWC stores, conflict-free weight reads, input broadcast).
+// A workgroup walks row tiles of 256/COUT*4 output columns of one window row.  The
+// input rows (with the zero halo) and all weights sit in LDS; thread = (column
+// group, cout) computes 4 consecutive columns x 1 channel, so one weight read
+// feeds 4 FMAs and the input reads are wave broadcasts.  Stores are coalesced NHWC.
 struct Conv1Params {
     const float *in; size_t in_win_stride;       // [B][H][W]
     float *out; size_t out_win_stride;
@@ -219,42 +221,66 @@ struct Conv1Params {
     const float *s1, *t1, *s2, *t2;
     int B, H, W, KH, KW, COUT;
 };
+#define C1_PPT 4
 __global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wl = smem;                            // [KH*KW][COUT]
     const int ntap = p.KH * p.KW;
+    const int groups = 256 / p.COUT;             // column groups per workgroup
+    const int TWc = groups * C1_PPT;             // output columns per tile
+    const int XW = TWc + p.KW - 1;               // staged input columns
+    float *wl = smem;                            // [ntap][COUT]
+    float *xt = smem + ntap * p.COUT;            // [KH][XW]
     for (int i = threadIdx.x; i < ntap * p.COUT; i += 256) wl[i] = p.w[i];
-    __syncthreads();
     const int pad_t = (p.KH - 1) / 2, pad_l = (p.KW - 1) / 2;
     const int co = threadIdx.x % p.COUT;
-    const int ppb = 256 / p.COUT;                // positions per block pass
-    const size_t hw = (size_t)p.H * p.W;
-    const size_t total = (size_t)p.B * hw;
+    const int pg = threadIdx.x / p.COUT;
+    const int tiles_w = (p.W + TWc - 1) / TWc;
+    const long total = (long)p.B * p.H * tiles_w;
     const float s1 = p.s1[co], t1 = p.t1[co];
     const float s2 = p.s2 ? p.s2[co] : 1.f, t2 = p.t2 ? p.t2[co] : 0.f;
-    for (size_t pos = (size_t)blockIdx.x * ppb + threadIdx.x / p.COUT; pos < total;
-         pos += (size_t)gridDim.x * ppb) {
-        const int b = (int)(pos / hw);
-        const int sp = (int)(pos - (size_t)b * hw);
-        const int r = sp / p.W, c = sp - r * p.W;
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int tc = (int)(tile % tiles_w);
+        long rest = tile / tiles_w;
+        const int r = (int)(rest % p.H);
+        const int b = (int)(rest / p.H);
+        const int c0 = tc * TWc;
         const float *x = p.in + (size_t)b * p.in_win_stride;
-        float acc = 0.f;
+        __syncthreads();                         // previous tile consumed (and wl visible)
+        for (int i = threadIdx.x; i < p.KH * XW; i += 256) {
+            const int dy = i / XW, cx = i - dy * XW;
+            const int gr = r + dy - pad_t, gc = c0 + cx - pad_l;
+            xt[i] = (gr >= 0 && gr < p.H && gc >= 0 && gc < p.W) ? x[(size_t)gr * p.W + gc] : 0.f;
+        }
+        __syncthreads();
+        float acc[C1_PPT];
+#pragma unroll
+        for (int q = 0; q < C1_PPT; ++q) acc[q] = 0.f;
         for (int dy = 0; dy < p.KH; ++dy) {
-            const int gr = r + dy - pad_t;
-            if (gr < 0 || gr >= p.H) continue;
+            const float *xr = xt + dy * XW + pg * C1_PPT;
+            const float *wr = wl + dy * p.KW * p.COUT + co;
             for (int dx = 0; dx < p.KW; ++dx) {
-                const int gc = c + dx - pad_l;
-                if (gc < 0 || gc >= p.W) continue;
-                acc = fmaf(x[(size_t)gr * p.W + gc], wl[(dy * p.KW + dx) * p.COUT + co], acc);
+                const float wv = wr[dx * p.COUT];
+#pragma unroll
+                for (int q = 0; q < C1_PPT; ++q) acc[q] = fmaf(xr[dx + q], wv, acc[q]);
             }
         }
-        float v = sigmoidf_(acc * s1 + t1);
-        if (p.sc) v = (v + p.sc[(size_t)b * p.sc_win_stride + (size_t)sp * p.COUT + co]) * s2 + t2;
-        p.out[(size_t)b * p.out_win_stride + (size_t)sp * p.COUT + co] = v;
+#pragma unroll
+        for (int q = 0; q < C1_PPT; ++q) {
+            const int c = c0 + pg * C1_PPT + q;
+            if (c >= p.W) continue;
+            const size_t sp = (size_t)r * p.W + c;
+            float v = sigmoidf_(acc[q] * s1 + t1);
+            if (p.sc) v = (v + p.sc[(size_t)b * p.sc_win_stride + sp * p.COUT + co]) * s2 + t2;
+            p.out[(size_t)b * p.out_win_stride + sp * p.COUT + co] = v;
+        }
     }
 }
 
 // ---- shortcut projection: BN(avgpool(conv1x1(x)))  (RDCNN.py:328-334) -----------
+// The 1x1 convolution and the average pool commute; pooling first cuts the
+// contraction work by the pool area.  A workgroup owns <= 64 output columns of one
+// output row: phase 1 pools the inputs into LDS (coalesced over channels), phase 2
+// contracts the pooled vectors with the [CIN][COUT] kernel (coalesced over cout).
 struct ProjParams {
     const float *in; size_t in_win_stride;       // [B][H][W][CIN]
     float *out; size_t out_win_stride;           // [B][HO][WO][COUT]
@@ -262,33 +288,36 @@ struct ProjParams {
     const float *s, *t;                          // folded: out = s*(sum) + t  (bias inside t)
     int B, H, W, CIN, COUT, PH, PW, HO, WO;
 };
+#define PJ_TW 64
 __global__ __launch_bounds__(256) void proj_kernel(ProjParams p) {
-    const size_t total = (size_t)p.B * p.HO * p.WO * p.COUT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [PJ_TW][CIN]
+    const int wo0 = blockIdx.x * PJ_TW;
+    const int ho = blockIdx.y, b = blockIdx.z;
+    const int nwo = min(PJ_TW, p.WO - wo0);
     const float inv = 1.0f / (float)(p.PH * p.PW);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int co = (int)(i % p.COUT);
-        size_t r = i / p.COUT;
-        const int wo = (int)(r % p.WO); r /= p.WO;
-        const int ho = (int)(r % p.HO);
-        const int b = (int)(r / p.HO);
-        const float *x = p.in + (size_t)b * p.in_win_stride;
-        float acc = 0.f;
+    const float *x = p.in + (size_t)b * p.in_win_stride;
+    for (int i = threadIdx.x; i < nwo * p.CIN; i += 256) {
+        const int wl = i / p.CIN, ci = i - wl * p.CIN;
+        const int wo = wo0 + wl;
+        float a = 0.f;
+        for (int dy = 0; dy < p.PH; ++dy)
+            for (int dx = 0; dx < p.PW; ++dx)
+                a += x[((size_t)(ho * p.PH + dy) * p.W + (wo * p.PW + dx)) * p.CIN + ci];
+        smem[i] = a * inv;
+    }
+    __syncthreads();
+    float *o = p.out + (size_t)b * p.out_win_stride + ((size_t)ho * p.WO + wo0) * p.COUT;
+    for (int i = threadIdx.x; i < nwo * p.COUT; i += 256) {
+        const int wl = i / p.COUT, co = i - wl * p.COUT;
+        float acc;
         if (p.w) {
-            for (int ci = 0; ci < p.CIN; ++ci) {
-                float a = 0.f;
-                for (int dy = 0; dy < p.PH; ++dy)
-                    for (int dx = 0; dx < p.PW; ++dx)
-                        a += x[((size_t)(ho * p.PH + dy) * p.W + (wo * p.PW + dx)) * p.CIN + ci];
-                acc = fmaf(a * inv, p.w[ci * p.COUT + co], acc);
-            }
+            acc = 0.f;
+            const float *pv = smem + wl * p.CIN;
+            for (int ci = 0; ci < p.CIN; ++ci) acc = fmaf(pv[ci], p.w[ci * p.COUT + co], acc);
         } else {
-            for (int dy = 0; dy < p.PH; ++dy)
-                for (int dx = 0; dx < p.PW; ++dx)
-                    acc += x[((size_t)(ho * p.PH + dy) * p.W + (wo * p.PW + dx)) * p.CIN + co];
-            acc *= inv;
+            acc = smem[wl * p.CIN + co];
         }
-        p.out[(size_t)b * p.out_win_stride + ((size_t)ho * p.WO + wo) * p.COUT + co] =
-            acc * p.s[co] + p.t[co];
+        o[i] = acc * p.s[co] + p.t[co];
     }
 }
 
@@ -313,43 +342,50 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
     }
 }
 
-// ---- Dense: y[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]); 8 windows per block --
-#define DN_MB 8
-#define DN_KC 256
-__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ x, int K,
-                                                     const float *__restrict__ w,
+// ---- Dense: C[M][N] = act(A[M][K] B[K][N] + bias[N]) on v_mfma_f32_32x32x2_f32 -----
+// 64x64 output tile per workgroup (4 waves, one 32x32 tile each), K in chunks of
+// 32 staged through LDS ([64][33] for A: conflict-free fragment reads).
+#define DN_KC 32
+__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ A, int K,
+                                                     const float *__restrict__ Bm,
                                                      const float *__restrict__ bias, int N,
-                                                     float *__restrict__ y, int B, int act) {
-    __shared__ float xs[DN_MB][DN_KC];
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int b0 = blockIdx.y * DN_MB;
-    float acc[DN_MB];
+                                                     float *__restrict__ Cm, int M, int act) {
+    __shared__ float as[64 * 33];
+    __shared__ float bs[DN_KC * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int mi = wid >> 1, ni = wid & 1;
+    f32x16 acc;
 #pragma unroll
-    for (int m = 0; m < DN_MB; ++m) acc[m] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += DN_KC) {
         __syncthreads();
-        for (int i = threadIdx.x; i < DN_MB * DN_KC; i += 256) {
-            const int m = i / DN_KC, kk = i - m * DN_KC;
-            xs[m][kk] = (b0 + m < B && k0 + kk < K) ? x[(size_t)(b0 + m) * K + k0 + kk] : 0.f;
+        for (int i = tid; i < 64 * DN_KC; i += 256) {
+            const int r = i / DN_KC, kk = i - r * DN_KC;
+            as[r * 33 + kk] = (m0 + r < M && k0 + kk < K) ? A[(size_t)(m0 + r) * K + k0 + kk] : 0.f;
+        }
+        for (int i = tid; i < DN_KC * 64; i += 256) {
+            const int kk = i >> 6, c = i & 63;
+            bs[i] = (k0 + kk < K && n0 + c < N) ? Bm[(size_t)(k0 + kk) * N + n0 + c] : 0.f;
         }
         __syncthreads();
-        if (n < N) {
-            const int kend = min(DN_KC, K - k0);
-            for (int kk = 0; kk < kend; ++kk) {
-                const float wv = w[(size_t)(k0 + kk) * N + n];
 #pragma unroll
-                for (int m = 0; m < DN_MB; ++m) acc[m] = fmaf(xs[m][kk], wv, acc[m]);
-            }
+        for (int kk = 0; kk < DN_KC; kk += 2) {
+            const float a = as[(mi * 32 + (lane & 31)) * 33 + kk + (lane >> 5)];
+            const float bv = bs[(kk + (lane >> 5)) * 64 + ni * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
         }
     }
+    const int n = n0 + ni * 32 + (lane & 31);
     if (n < N) {
         const float bv = bias[n];
 #pragma unroll
-        for (int m = 0; m < DN_MB; ++m) {
-            if (b0 + m < B) {
-                float v = acc[m] + bv;
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (m < M) {
+                float v = acc[e] + bv;
                 if (act == 1) v = sigmoidf_(v);
-                y[(size_t)(b0 + m) * N + n] = v;
+                Cm[(size_t)m * N + n] = v;
             }
         }
     }
@@ -774,7 +810,8 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         float *sb = pick(cur, p0, o);
                         ProjParams pp{p0, p0_stride, sb, (size_t)pr.HO * pr.WO * pr.cout, pr.w, pr.s, pr.t,
                                       Bc, pr.H, pr.W, pr.cin, pr.cout, pr.ph, pr.pw, pr.HO, pr.WO};
-                        proj_kernel<<<grid_for((size_t)Bc * pr.HO * pr.WO * pr.cout), 256, 0, st>>>(pp);
+                        proj_kernel<<<dim3((pr.WO + PJ_TW - 1) / PJ_TW, pr.HO, Bc), 256,
+                                      (size_t)PJ_TW * pr.cin * sizeof(float), st>>>(pp);
                         sc = sb; sc_stride = (size_t)pr.HO * pr.WO * pr.cout;
                     } else {
                         sc = p0; sc_stride = p0_stride;
@@ -792,10 +829,11 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                    c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                    Bc, H, W, c.kh, c.kw, c.cout};
-                    const size_t lds = (size_t)c.kh * c.kw * c.cout * 4;
-                    const int ppb = 256 / c.cout;
-                    const size_t blocks = ((size_t)Bc * H * W + ppb - 1) / ppb;
-                    conv1_kernel<<<(unsigned)std::min<size_t>(blocks, 1u << 20), 256, lds, st>>>(cp);
+                    const int groups = 256 / c.cout;
+                    const size_t lds = ((size_t)c.kh * c.kw * c.cout +
+                                        (size_t)c.kh * (groups * C1_PPT + c.kw - 1)) * 4;
+                    const size_t tiles = (size_t)Bc * H * ((W + groups * C1_PPT - 1) / (groups * C1_PPT));
+                    conv1_kernel<<<(unsigned)std::min<size_t>(tiles, 8192), 256, lds, st>>>(cp);
                     AMT_LAUNCH_CHECK();
                 } else {
                     ConvParams cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
@@ -823,9 +861,9 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
             }
             flat_off += tw.out_h * tw.out_w * tw.out_c;
         }
-        dense_kernel<<<dim3((DU + 255) / 256, (Bc + DN_MB - 1) / DN_MB), 256, 0, st>>>(
+        dense_kernel<<<dim3((DU + 63) / 64, (Bc + 63) / 64), 256, 0, st>>>(
             flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1);
-        dense_kernel<<<dim3((K + 255) / 256, (Bc + DN_MB - 1) / DN_MB), 256, 0, st>>>(
+        dense_kernel<<<dim3((K + 63) / 64, (Bc + 63) / 64), 256, 0, st>>>(
             d1, DU, net->d2w, net->d2b, K, lg, Bc, 0);
         head_output_kernel<<<(Bc + 63) / 64, 64, 0, st>>>(lg, y + (size_t)b0 * K, Bc, K, d.out_lo, d.out_hi);
         if (logits)

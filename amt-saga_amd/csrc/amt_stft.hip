@@ -53,7 +53,9 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
         if (t0 >= T) break;                       // uniform across the block
         const bool has2 = (t0 + 1) < T;
         const int s0 = t0 * hop - pad;            // first sample of frame t0
-        auto load = [&](int n) -> float2 {
+        // interior pairs (both frames inside the signal) skip the reflect index map
+        const bool interior = s0 >= 0 && (s0 + hop + N) <= L && has2;
+        auto load_edge = [&](int n) -> float2 {
             const float w = 0.5f - 0.5f * tw[n].x;
             int i0 = s0 + n;
             int i1 = i0 + hop;
@@ -64,7 +66,13 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
             const float c = has2 ? wv[i1] : 0.f;
             return make_float2(a * w, c * w);
         };
-        fft_block<N, false>(buf, tw, load);
+        const float *w0 = wv + s0;
+        auto load_in = [&](int n) -> float2 {
+            const float w = 0.5f - 0.5f * tw[n].x;
+            return make_float2(w0[n] * w, w0[n + hop] * w);
+        };
+        if (interior) fft_block<N, false>(buf, tw, load_in);
+        else fft_block<N, false>(buf, tw, load_edge);
 
         float *m0 = mg + (size_t)t0 * ldf;
         float *m1 = m0 + ldf;
@@ -77,11 +85,16 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
                 const float2 x0 = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
                 const float2 d = csub(zk, zm);
                 const float2 x1 = make_float2(0.5f * d.y, -0.5f * d.x);
-                a0 = sqrtf(x0.x * x0.x + x0.y * x0.y);
-                a1 = sqrtf(x1.x * x1.x + x1.y * x1.y);
+                // |X| = n2 * rsq(n2), X/|X| = X * rsq(n2)  (v_rsq_f32, ~1 ulp); 0 -> (0, 1+0i)
+                const float n0 = x0.x * x0.x + x0.y * x0.y;
+                const float n1 = x1.x * x1.x + x1.y * x1.y;
+                const float r0 = n0 > 1e-36f ? __builtin_amdgcn_rsqf(n0) : 0.f;
+                const float r1 = n1 > 1e-36f ? __builtin_amdgcn_rsqf(n1) : 0.f;
+                a0 = n0 * r0;
+                a1 = n1 * r1;
                 if (WITH_PHASE) {
-                    p0 = a0 > 0.f ? make_float2(x0.x / a0, x0.y / a0) : make_float2(1.f, 0.f);
-                    p1 = a1 > 0.f ? make_float2(x1.x / a1, x1.y / a1) : make_float2(1.f, 0.f);
+                    p0 = r0 > 0.f ? make_float2(x0.x * r0, x0.y * r0) : make_float2(1.f, 0.f);
+                    p1 = r1 > 0.f ? make_float2(x1.x * r1, x1.y * r1) : make_float2(1.f, 0.f);
                 }
                 lmax = fmaxf(lmax, a0);
                 if (has2) lmax = fmaxf(lmax, a1);
