@@ -78,6 +78,7 @@ PROTOTYPES = {
     'amt_rdcnn_workspace_bytes': (C.c_size_t, [vp, C.c_int]),
     'amt_rdcnn_forward': (C.c_int, [vp, C.POINTER(vp), C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'amt_rdcnn_flops_per_window': (C.c_double, [vp]),
+    'amt_rdcnn_set_mode': (C.c_int, [vp, C.c_int]),
     'amt_rdcnn_profile': (C.c_int, [vp, C.c_int]),
     'amt_rdcnn_profile_read': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, c_int32_p, C.c_int]),
 }

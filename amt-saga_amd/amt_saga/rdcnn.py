@@ -29,6 +29,9 @@ from . import _lib
 from .device import empty, ptr, require_gpu, stream_ptr, to_dev
 
 
+DEFAULT_MODE = int(__import__('os').environ.get('AMT_CONV_MODE', '0'))
+
+
 def _to_list(single):
     """RDCNN.py:288-302."""
     if single is None:
@@ -224,6 +227,7 @@ class res_net:
                                         self._blob.ctypes.data_as(C.c_void_p), self._blob.size))
         self._net = h
         self._lib = lib
+        _lib.check(lib.amt_rdcnn_set_mode(h, int(getattr(self, 'mode', DEFAULT_MODE))))
 
     def _release(self):
         if getattr(self, '_net', None) is not None:
@@ -248,6 +252,12 @@ class res_net:
     def flops_per_window(self):
         self._ensure()
         return float(self._lib.amt_rdcnn_flops_per_window(self._net))
+
+    def set_mode(self, mode):
+        """0 = f32 MFMA convolutions, 1 = split-bf16 (f32-equivalent) convolutions."""
+        self.mode = int(mode)
+        if self._net is not None:
+            _lib.check(self._lib.amt_rdcnn_set_mode(self._net, self.mode))
 
     # ---- measurement hook ------------------------------------------------------------
     def profile(self, enable=True):

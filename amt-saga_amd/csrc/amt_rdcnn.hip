@@ -27,6 +27,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -202,6 +203,291 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             for (int nt = 0; nt < NT; ++nt) {
                 float v = sigmoidf_(acc[mt][nt][e] * s1[nt] + t1[nt]);
                 if (scp) v = (v + scp[nt * 32]) * s2[nt] + t2[nt];
+                o[nt * 32] = v;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Split-bf16 convolution ("bf16x6"): fp32-equivalent products on the bf16 MFMA pipe.
+// Every f32 operand x is split exactly into three bf16 terms x = x1 + x2 + x3
+// (8 + 8 + 8 mantissa bits); the product x*y is the six terms with i + j <= 4
+// (x1y1, x1y2, x2y1, x1y3, x2y2, x3y1), each exact in the MFMA's f32 accumulate; the
+// dropped terms are <= 2^-26 |xy|, below f32 rounding.  Six v_mfma_f32_32x32x16_bf16
+// per 16-deep k-block replace eight v_mfma_f32_32x32x2_f32: 2.67x fewer matrix-pipe
+// cycles at f32 accuracy (bf16 MFMA = 16x the f32 MFMA rate, MI355X_MICROARCH.md).
+//   * 512-thread workgroup, 8 waves x one 32-position M-tile; same tile geometry,
+//     halo staging and epilogue as the f32 kernel;
+//   * activations stay f32 in HBM and are split once per workgroup while staging
+//     into LDS as [pos][plane(3)][32 ch] bf16 (208-B pitch: conflict-free
+//     ds_read_b128 A fragments, lane = position, 8 consecutive channels);
+//   * weights are split on the host and laid out so a (tap, k-block, plane, N-tile)
+//     fragment is one conflict-free ds_read_b128 per lane.
+// ---------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define BX_CC 16                             // channels per staged chunk (one bf16 k-block)
+#define BX_PSTRIDE 112                      // bytes per staged position: 3 planes x 16 ch x 2 B + 16 pad
+__host__ __device__ __forceinline__ int bx_row_pitch(int TW, int TWin) {
+    return TWin + (((TW - TWin) % 16) + 16) % 16;
+}
+
+__host__ __device__ __forceinline__ unsigned short amt_f2bf(float x) {
+    unsigned int u;
+#ifdef __HIP_DEVICE_COMPILE__
+    u = __float_as_uint(x);
+#else
+    memcpy(&u, &x, 4);
+#endif
+    u += 0x7FFFu + ((u >> 16) & 1u);         // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+__host__ __device__ __forceinline__ float amt_bf2f(unsigned short h) {
+    unsigned int u = ((unsigned int)h) << 16;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+__host__ __device__ __forceinline__ void amt_split3(float x, unsigned short &h1, unsigned short &h2,
+                                                    unsigned short &h3) {
+    h1 = amt_f2bf(x);
+    const float r1 = x - amt_bf2f(h1);
+    h2 = amt_f2bf(r1);
+    const float r2 = r1 - amt_bf2f(h2);
+    h3 = amt_f2bf(r2);
+}
+
+template <int KH, int KW, int CIN, int COUT>
+__global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const uint4 *__restrict__ w16) {
+    // Geometry: 8 waves x one 32-position M-tile = 256 output positions per workgroup; the
+    // contraction is walked in 16-channel chunks (one bf16 k-block per tap), so the staged
+    // input tile is [pos][plane(3)][16 ch] bf16 = 112 B per position and TWO workgroups fit
+    // a CU: one stages / stores while the other keeps the matrix pipe busy.
+    constexpr int NT = COUT / 32;
+    constexpr int NCHUNK = CIN / BX_CC;
+    constexpr int NTAPS = KH * KW;
+    constexpr int PCAP = 256;
+    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
+    constexpr int TPS = (NT == 1 && NTAPS % 2 == 0) ? 2 : 1;       // taps per weight slab
+    constexpr int NSLAB = NTAPS / TPS;
+    constexpr int SLAB_V4 = TPS * 3 * NT * 64;                      // uint4 per slab (fragment = 64 lanes x 16 B)
+    constexpr int WV4 = (SLAB_V4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [3][SLAB_V4]
+    int *pos_sp = reinterpret_cast<int *>(wbuf + 3 * SLAB_V4);      // [PCAP]
+    int *pos_win = pos_sp + PCAP;
+    char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][112 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int THin = p.TH + KH - 1, TWin = p.TW + KW - 1;
+    // LDS row pitch (in positions) == TW (mod 16): consecutive flattened tile positions stay an
+    // odd number (7) of 16-byte slots apart across the row wrap -> conflict-free b128 reads
+    const int RP = bx_row_pitch(p.TW, TWin);
+    int bid = blockIdx.x;
+    const int tc = bid % p.tiles_w; bid /= p.tiles_w;
+    const int tr = bid % p.tiles_h; bid /= p.tiles_h;
+    const int win0 = bid * p.NWIN;
+    const int r0 = tr * p.TH, c0 = tc * p.TW;
+    const int ptile = p.TH * p.TW;
+
+    for (int q = tid; q < PCAP; q += 512) {
+        const int w_ = q / ptile, rem = q - w_ * ptile;
+        const int r = rem / p.TW, c = rem - r * p.TW;
+        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
+        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
+        pos_win[q] = win0 + w_;
+    }
+    int abase;
+    {
+        int q = wid * 32 + (lane & 31);
+        int w_ = q / ptile, rem = q - w_ * ptile;
+        int r = rem / p.TW, c = rem - r * p.TW;
+        if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
+        abase = ((w_ * THin + r) * RP + c) * BX_PSTRIDE + (lane >> 5) * 16;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        __syncthreads();
+        // ---- stage + split the input tile (16 channels) --------------------------------
+        // work item = (halo row, column, 8-channel half); items are dealt round-robin to the
+        // 512 threads and ALL of a thread's global loads are issued before the first split,
+        // so the tile costs one memory latency instead of one per halo row.
+        {
+            const int nrow = p.NWIN * THin;
+            const int items = nrow * TWin * 2;
+            constexpr int MAXIT = 2;
+            for (int it0 = 0; it0 < items; it0 += 512 * MAXIT) {
+                float4 v0[MAXIT], v1[MAXIT];
+                int dsto[MAXIT];
+#pragma unroll
+                for (int u = 0; u < MAXIT; ++u) {
+                    const int it = it0 + u * 512 + tid;
+                    v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u]; dsto[u] = -1;
+                    if (it < items) {
+                        const int cg = it & 1;
+                        const int pc = it >> 1;
+                        const int wr = pc / TWin, ci = pc - wr * TWin;
+                        const int w_ = wr / THin, ri = wr - w_ * THin;
+                        const int gr = r0 - PAD_T + ri, gc = c0 - PAD_L + ci, gw = win0 + w_;
+                        dsto[u] = (wr * RP + ci) * BX_PSTRIDE + cg * 16;
+                        if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
+                            const float4 *src = reinterpret_cast<const float4 *>(
+                                p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + ch * BX_CC + cg * 8);
+                            v0[u] = src[0]; v1[u] = src[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MAXIT; ++u) {
+                    if (dsto[u] < 0) continue;
+                    const float v[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                    unsigned short h[3][8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amt_split3(v[e], h[0][e], h[1][e], h[2][e]);
+                    char *dst = in_lds + dsto[u];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        uint4 pk;
+                        pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+                        pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+                        pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+                        pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+                        *reinterpret_cast<uint4 *>(dst + pl * 32) = pk;
+                    }
+                }
+            }
+        }
+        // ---- K loop over weight slabs: 3 LDS buffers, global prefetch two slabs ahead ------
+        //  step s: issue the loads of slab s+2 (registers), run slab s from LDS, then park
+        //  slab s+1 (loaded during step s-1: two slab-times of latency budget) into LDS.
+        //  The loads are inline asm on purpose: hipcc sinks an ordinary prefetch load down to
+        //  its use and waits vmcnt(0) there (and it waits vmcnt(0) before every ds_read while a
+        //  global_load_lds is in flight).  The kernel must stay spill-free: a spill of an
+        //  in-flight asm destination would save stale data (checked by the build).
+        {
+            const uint4 *src = w16 + (size_t)(ch * NSLAB) * SLAB_V4;
+            for (int i = tid; i < SLAB_V4; i += 512) wbuf[i] = src[i];
+        }
+        u32x4 wpa[WV4], wpb[WV4];
+        auto issue = [&](u32x4 (&wp)[WV4], int slab) {
+            const uint4 *src = w16 + (size_t)(ch * NSLAB + slab) * SLAB_V4;
+#pragma unroll
+            for (int i = 0; i < WV4; ++i) {
+                const uint4 *ptr = src + min(tid + i * 512, SLAB_V4 - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(ptr) : "memory");
+            }
+        };
+        auto park = [&](u32x4 (&wp)[WV4], int slab) {
+            u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + (slab % 3) * SLAB_V4);
+#pragma unroll
+            for (int i = 0; i < WV4; ++i)
+                if (tid + i * 512 < SLAB_V4) dst[tid + i * 512] = wp[i];
+        };
+        if (NSLAB > 1) issue(wpa, 1);                          // slab 1, parked at the end of step 0
+        __syncthreads();
+        auto step = [&](int s_, u32x4 (&w_next)[WV4], u32x4 (&w_new)[WV4]) {
+            if (s_ + 2 < NSLAB) issue(w_new, s_ + 2);
+            const uint4 *wb = wbuf + (s_ % 3) * SLAB_V4 + lane;
+            union U { uint4 u; bf16x8 v; };
+            U a[TPS][3];
+            U b[TPS][3][NT];
+            {
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt) {
+                    const int tap = s_ * TPS + tt;
+                    const int dy = tap / KW, dx = tap - dy * KW;
+                    const char *ab = in_lds + abase + (dy * RP + dx) * BX_PSTRIDE;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        a[tt][pl].u = *reinterpret_cast<const uint4 *>(ab + pl * 32);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) b[tt][pl][nt].u = wb[((tt * 3 + pl) * NT + nt) * 64];
+                    }
+                }
+            }
+            {
+#pragma unroll
+                for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        // smallest terms first
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][2].v, b[tt][0][nt].v, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][1].v, b[tt][1][nt].v, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][0].v, b[tt][2][nt].v, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][1].v, b[tt][0][nt].v, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][0].v, b[tt][1][nt].v, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt][0].v, b[tt][0][nt].v, acc[nt], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // the MFMA chain stays above the slab hand-over
+            if (s_ + 1 < NSLAB) {
+                // retire slab s+1's loads; slab s+2's (the WV4 newest) may stay in flight
+                if (s_ + 2 < NSLAB) {
+                    if constexpr (WV4 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if constexpr (WV4 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                park(w_next, s_ + 1);
+            }
+            __syncthreads();
+        };
+        static_assert(NSLAB % 2 == 0, "slab loop is unrolled by two");
+        for (int s_ = 0; s_ < NSLAB; s_ += 2) {
+            step(s_, wpa, wpb);
+            step(s_ + 1, wpb, wpa);
+        }
+    }
+    // ---- epilogue (as in the f32 kernel, MT = 1) ---------------------------------------------
+    const int j = lane & 31;
+    float s1[NT], t1[NT], s2[NT], t2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = p.s1[nt * 32 + j]; t1[nt] = p.t1[nt * 32 + j];
+        s2[nt] = p.s2 ? p.s2[nt * 32 + j] : 1.f;
+        t2[nt] = p.t2 ? p.t2[nt * 32 + j] : 0.f;
+    }
+    // per batch of EPB rows: all shortcut loads first, then the arithmetic and the stores
+    constexpr int EPB = 4;
+#pragma unroll
+    for (int half = 0; half < 16 / EPB; ++half) {
+        int spq[EPB], gwq[EPB];
+        float scv[EPB][NT];
+#pragma unroll
+        for (int e8 = 0; e8 < EPB; ++e8) {
+            const int e = half * EPB + e8;
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int q = wid * 32 + row;
+            spq[e8] = pos_sp[q];
+            gwq[e8] = pos_win[q];
+        }
+        if (p.sc) {
+#pragma unroll
+            for (int e8 = 0; e8 < EPB; ++e8) {
+                const float *scp = p.sc + (size_t)gwq[e8] * p.sc_win_stride + (size_t)max(spq[e8], 0) * COUT + j;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) scv[e8][nt] = spq[e8] >= 0 ? scp[nt * 32] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e8 = 0; e8 < EPB; ++e8) {
+            const int e = half * EPB + e8;
+            if (spq[e8] < 0) continue;
+            float *o = p.out + (size_t)gwq[e8] * p.out_win_stride + (size_t)spq[e8] * COUT + j;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = sigmoidf_(acc[nt][e] * s1[nt] + t1[nt]);
+                if (p.sc) v = (v + scv[e8][nt]) * s2[nt] + t2[nt];
                 o[nt * 32] = v;
             }
         }
@@ -423,6 +709,11 @@ struct ConvOp {
     int pool_after = 0;        // 1 => maxpool (ph, pw) follows
     int TH = 0, TW = 0, NWIN = 1, MT = 2;
     size_t lds = 0;
+    // split-bf16 variant (null when not built for this layer)
+    uint4 *w16 = nullptr;
+    int TH16 = 0, TW16 = 0, NWIN16 = 1;
+    size_t lds16 = 0;
+    double eff32 = 0, eff16 = 0;
 };
 struct ProjOp {
     int cin, cout, H, W, ph, pw, HO, WO;
@@ -449,6 +740,7 @@ struct amt_rdcnn {
     float *d1w = nullptr, *d1b = nullptr, *d2w = nullptr, *d2b = nullptr;
     int flat = 0;
     double flops = 0;
+    mutable int mode = 0;      // 0: f32 MFMA, 1: split-bf16 where built
 };
 
 static int upload(amt_rdcnn *n, const std::vector<float> &h, float **out) {
@@ -481,7 +773,7 @@ static void choose_tile(ConvOp &c) {
             const double tiles = (double)((c.H + TH - 1) / TH) * ((c.W + TW - 1) / TW) / NWIN;
             double eff = (double)c.H * c.W / (tiles * pcap);
             if (lds > 78 * 1024) eff *= 0.93;          // prefer two workgroups per CU
-            if (eff > best + 1e-9) { best = eff; c.TH = TH; c.TW = TW; c.NWIN = NWIN; c.MT = MT; c.lds = lds; }
+            if (eff > best + 1e-9) { best = eff; c.TH = TH; c.TW = TW; c.NWIN = NWIN; c.MT = MT; c.lds = lds; c.eff32 = eff; }
         };
         if (c.H * c.W <= pcap) {
             for (int nw = pcap / (c.H * c.W); nw >= 1; --nw) consider(c.H, c.W, nw);
@@ -496,6 +788,69 @@ static void choose_tile(ConvOp &c) {
             if (TW2 >= 1 && TW2 <= TW) consider(TH, TW2, 1);
         }
     }
+}
+
+
+static size_t slab16_bytes(const ConvOp &c) {
+    const int NT = c.cout / 32, ntaps = c.kh * c.kw;
+    const int tps = (NT == 1 && ntaps % 2 == 0) ? 2 : 1;
+    return (size_t)tps * 3 * NT * 64 * 16;
+}
+static void choose_tile16(ConvOp &c) {
+    double best = -1;
+    const int pcap = 256;
+    auto consider = [&](int TH, int TW, int NWIN) {
+        const size_t posin = (size_t)NWIN * (TH + c.kh - 1) * bx_row_pitch(TW, TW + c.kw - 1);
+        const size_t lds = posin * BX_PSTRIDE + 3 * slab16_bytes(c) + (size_t)pcap * 8;
+        if (lds > 79 * 1024) return;                    // two workgroups per CU
+        const double tiles = (double)((c.H + TH - 1) / TH) * ((c.W + TW - 1) / TW) / NWIN;
+        const double eff = (double)c.H * c.W / (tiles * pcap);
+        if (eff > best + 1e-9) { best = eff; c.TH16 = TH; c.TW16 = TW; c.NWIN16 = NWIN; c.lds16 = lds; c.eff16 = eff; }
+    };
+    if (c.H * c.W <= pcap)
+        for (int nw = pcap / (c.H * c.W); nw >= 1; --nw) consider(c.H, c.W, nw);
+    for (int TH = 1; TH <= c.H && TH <= pcap; ++TH) {
+        int TW = pcap / TH;
+        if (TW > c.W) TW = c.W;
+        if (TW >= 1) consider(TH, TW, 1);
+        const int nct = (c.W + TW - 1) / TW;
+        const int TW2 = (c.W + nct - 1) / nct;
+        if (TW2 >= 1 && TW2 <= TW) consider(TH, TW2, 1);
+    }
+}
+
+template <int KH, int KW, int CIN, int COUT>
+static int launch_conv16_t(const ConvOp &c, ConvParams p, hipStream_t st) {
+    auto kern = conv_bf16x6_kernel<KH, KW, CIN, COUT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        attr_set = true;
+    }
+    p.TH = c.TH16; p.TW = c.TW16; p.NWIN = c.NWIN16;
+    p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
+    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
+    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
+    kern<<<grid, 512, c.lds16, st>>>(p, c.w16);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+template <int KH, int KW>
+static int launch_conv16_k(const ConvOp &c, const ConvParams &p, hipStream_t st) {
+    if (c.cin == 32 && c.cout == 32) return launch_conv16_t<KH, KW, 32, 32>(c, p, st);
+    if (c.cin == 32 && c.cout == 64) return launch_conv16_t<KH, KW, 32, 64>(c, p, st);
+    if (c.cin == 64 && c.cout == 64) return launch_conv16_t<KH, KW, 64, 64>(c, p, st);
+    return AMT_E_UNSUPPORTED;
+}
+static bool conv16_supported(const ConvOp &c) {
+    return (c.cin == 32 && c.cout == 32) || (c.cin == 32 && c.cout == 64) || (c.cin == 64 && c.cout == 64);
+}
+static int launch_conv16(const ConvOp &c, const ConvParams &p, hipStream_t st) {
+    if (c.kh == 4 && c.kw == 16) return launch_conv16_k<4, 16>(c, p, st);
+    if (c.kh == 4 && c.kw == 2) return launch_conv16_k<4, 2>(c, p, st);
+    if (c.kh == 2 && c.kw == 2) return launch_conv16_k<2, 2>(c, p, st);
+    return AMT_E_UNSUPPORTED;
 }
 
 template <int KH, int KW, int CIN, int COUT, int MT>
@@ -642,6 +997,42 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                 RD_TRY(upload(n, wa, &c.w));
                 choose_tile(c);
                 if (c.TH == 0) { amt_rdcnn_destroy(n); return AMT_E_UNSUPPORTED; }
+                if (conv16_supported(c)) {
+                    choose_tile16(c);
+                    // worth it only if 2.67x fewer matrix cycles survive the tile efficiency
+                    if (c.TH16 > 0 && c.eff16 * 2.67 > c.eff32 * 1.15) {
+                        const int tps = (NT == 1 && ntap % 2 == 0) ? 2 : 1;
+                        const int nslab = ntap / tps;
+                        // [chunk16][slab][tt][plane][nt][h][col][8] bf16
+                        const int nch16 = C / BX_CC;
+                        std::vector<unsigned short> w16((size_t)nch16 * ntap * 3 * NT * 2 * 32 * 8);
+                        for (int ch = 0; ch < nch16; ++ch)
+                            for (int sl = 0; sl < nslab; ++sl)
+                                for (int tt = 0; tt < tps; ++tt)
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        for (int h = 0; h < 2; ++h)
+                                            for (int col = 0; col < 32; ++col)
+                                                for (int jj = 0; jj < 8; ++jj) {
+                                                    const int tap = sl * tps + tt;
+                                                    const int cin_i = ch * BX_CC + 8 * h + jj;
+                                                    const float wv = kern[((size_t)tap * C + cin_i) * fo + nt * 32 + col];
+                                                    unsigned short hh[3];
+                                                    amt_split3(wv, hh[0], hh[1], hh[2]);
+                                                    for (int pl = 0; pl < 3; ++pl) {
+                                                        const size_t idx =
+                                                            (((((((size_t)ch * nslab + sl) * tps + tt) * 3 + pl) * NT + nt) * 2 + h) * 32 + col) * 8 + jj;
+                                                        w16[idx] = hh[pl];
+                                                    }
+                                                }
+                        void *d16 = nullptr;
+                        if (hipMalloc(&d16, w16.size() * 2) != hipSuccess) { amt_rdcnn_destroy(n); return AMT_E_NOMEM; }
+                        n->allocs.push_back(static_cast<float *>(d16));
+                        if (hipMemcpy(d16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                            amt_rdcnn_destroy(n); return AMT_E_HIP;
+                        }
+                        c.w16 = static_cast<uint4 *>(d16);
+                    }
+                }
             }
             n->flops += 2.0 * H * W * (double)kh * kw * C * fo;
             C = fo;
@@ -702,6 +1093,12 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
 }
 
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net) { return net ? net->flops : 0.0; }
+
+int amt_rdcnn_set_mode(amt_rdcnn *net, int mode) {
+    if (!net || mode < 0 || mode > 1) return AMT_E_INVALID;
+    net->mode = mode;
+    return AMT_OK;
+}
 
 int amt_rdcnn_profile(amt_rdcnn *net, int enable) {
     if (!net) return AMT_E_INVALID;
@@ -840,7 +1237,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                   Bc, H, W, c.TH, c.TW, c.NWIN, (H + c.TH - 1) / c.TH,
                                   (W + c.TW - 1) / c.TW};
-                    const int rc = launch_conv(c, cp, st);
+                    const int rc = (net->mode == 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
                 }
                 if (net->prof_on) {

@@ -218,6 +218,12 @@ size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B);
 int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B,
                       float *y, float *logits, void *workspace,
                       size_t workspace_bytes, void *stream);
+/* Arithmetic of the convolutions: 0 = v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate);
+ * 1 = "split-bf16": every f32 operand is split exactly into three bf16 terms and the
+ * six significant cross products run on v_mfma_f32_32x32x16_bf16 with f32
+ * accumulation -- same accuracy class as f32 (dropped terms <= 2^-26), 2.67x fewer
+ * matrix-pipe cycles.  Layers the split kernel is not built for keep mode 0. */
+int amt_rdcnn_set_mode(amt_rdcnn *net, int mode);
 /* FLOPs (2*MAC) of one window's forward, for roofline accounting */
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net);
 /* Measurement hook: when enabled, every convolution launch of amt_rdcnn_forward

@@ -24,7 +24,17 @@ def _inputs(shape, B, seed):
     return (rng.random((B,) + tuple(shape)) ** 2).astype(np.float32)
 
 
-def _check_head(env, head, cfg, B, seed, near_tie=0.02):
+def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1)):
+    """Both convolution arithmetics (f32 MFMA, split-bf16) against the oracle."""
+    out = None
+    for mode in modes:
+        head.set_mode(mode)
+        out = _check_head_mode(env, head, cfg, B, seed, near_tie)
+    head.set_mode(0)
+    return out
+
+
+def _check_head_mode(env, head, cfg, B, seed, near_tie):
     xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
     dev = [env['torch'].from_numpy(x).cuda() for x in xs]
     y, lg = head.predict_device(dev, return_logits=True)
@@ -105,6 +115,13 @@ def test_timing_head_n2048_batch_independent(env):
     assert np.array_equal(y[perm], y2)
     y3 = h.predict_device([x[:1].contiguous()]).cpu().numpy()
     assert np.array_equal(y[:1], y3)
+    # split-bf16 convolutions: same properties, and within 1e-4 of the f32-MFMA result
+    h.set_mode(1)
+    z = h.predict_device([x]).cpu().numpy()
+    z2 = h.predict_device([x[torch.from_numpy(perm).cuda()].contiguous()]).cpu().numpy()
+    assert np.array_equal(z[perm], z2)
+    assert np.abs(z - y).max() / np.abs(y).max() < 1e-4
+    h.set_mode(0)
 
 
 def test_classify_contract(env):

@@ -108,3 +108,32 @@ def test_missing_library_is_an_error(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_split_bf16_kernels_are_spill_free():
+    """The split-bf16 conv kernels prefetch weights with inline-asm loads whose
+    destination registers must never be spilled while in flight (a spill would save
+    stale data): require zero VGPR spills / scratch for every instantiation."""
+    import shutil
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'amt-saga_amd', 'csrc', 'amt_rdcnn.hip')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math',
+           '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
+           '-I' + os.path.join(ROOT, 'amt-saga_amd', 'csrc'), '-c', src, '-o', os.devnull,
+           '-Rpass-analysis=kernel-resource-usage']
+    out = subprocess.run(cmd, capture_output=True, text=True).stderr
+    blocks = out.split('Function Name: ')[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if 'conv_bf16x6_kernel' not in name:
+            continue
+        seen += 1
+        spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
+        scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1))
+        vgpr = int(re.search(r'\bVGPRs: (\d+)', b).group(1))
+        assert spill == 0 and scratch == 0, (name, spill, scratch)
+        assert vgpr <= 128, (name, vgpr)          # 4 waves per SIMD = two workgroups per CU
+    assert seen >= 9
