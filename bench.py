@@ -46,6 +46,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense FP32 matrix peak
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense BF16 matrix peak
 
 
 def build(workload, B):
@@ -100,6 +101,8 @@ def main():
     ap.add_argument('--windows', type=int, default=0, help='windows per GPU (default: the workload size)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1),
+                    help='1 = split-bf16 convolutions (f32-equivalent, default), 0 = f32 MFMA')
     args = ap.parse_args()
 
     from amt_saga import dist as adist, synth
@@ -110,6 +113,10 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.windows or wl['B']
     p, loop = build(wl, B)
+    if args.conv_mode is not None:
+        for n in loop.nets.values():
+            n.set_mode(args.conv_mode)
+    conv_mode = int(getattr(next(iter(loop.nets.values())), 'mode', 0)) if loop.nets else 0
     L = p.H * (p.timing_frames - 1)                         # 263,680 samples -> exactly 516 frames
 
     # synthetic windows, generated on the device (inputs resident in HBM before timing)
@@ -175,9 +182,27 @@ def main():
     dom = by_class[dom_key]
     conv_ms_total = sum(a['ms'] for a in by_class.values())
     achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-    roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
-                    frac=round(achieved_tf / MFMA_F32_PEAK_TF, 4), traffic=None,
-                    kernel='conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)' % dom_key,
+    split = conv_mode == 1 and dom_key[2] <= 64
+    # split-bf16: every algorithmic f32 MAC costs six bf16 MFMA MACs, so the MFMA roof for the
+    # ALGORITHMIC flops of this kernel is the dense bf16 peak / 6
+    peak_tf = round(MFMA_BF16_PEAK_TF / 6.0, 1) if split else MFMA_F32_PEAK_TF
+    kname = ('conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)'
+             if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf)).get('conv_bf16x6' if split else 'conv_mfma')
+            if t:
+                traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 512))
+        except Exception:
+            traffic = None
+    roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=peak_tf, unit='TFLOP/s',
+                    frac=round(achieved_tf / peak_tf, 4), traffic=traffic, kernel=kname,
+                    peak_note=('dense bf16 MFMA peak 2500 / 6 MFMAs per f32-equivalent product block'
+                               if split else 'dense f32 MFMA peak'),
+                    executed_mfma_tflops=round(achieved_tf * (6 if split else 1), 1),
+                    vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2))
     F, T, ldf = p.N // 2 + 1, p.timing_frames, (p.N // 2 + 1 + 3) & ~3
@@ -206,7 +231,8 @@ def main():
             'metric': 'audio windows/sec (44.1 kHz, 2048-pt STFT) through full detect->subtract loop',
             'value': round(value, 2), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if conv_mode == 0 else 'f32 (conv: split-bf16 x3 operands, f32 accumulate)',
             'data': 'synthetic (additive-synth windows, seeded random-init weights)',
             'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
                        'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
