@@ -102,6 +102,7 @@ class res_net:
         self._net = None
         self._ws = None
         self.weights = None
+        self.mode = DEFAULT_MODE
         self.layout = self._walk()
         if weights_load_checkpoint_filename is not None:
             self.load_weights(weights_load_checkpoint_filename)

@@ -44,6 +44,8 @@ struct ConvParams {
     int B, H, W;
     int TH, TW, NWIN;                            // workgroup tile
     int tiles_h, tiles_w;
+    int cout_total;                              // channels of the output tensor (>= the kernel's COUT
+                                                 // when the layer is split over blockIdx.y N-slices)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -99,7 +101,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
     constexpr int WV4 = WSLAB / 4 / 256;          // float4 per thread per slab (1, 2 or 4)
     static_assert(WSLAB % (4 * 256) == 0, "slab split");
-    const float4 *wg4 = reinterpret_cast<const float4 *>(p.w);
+    // N-slice of this workgroup (layers whose output-tile grid cannot fill the chip are split
+    // over blockIdx.y into COUT-wide channel slices, each with its own weight block)
+    const int cout_off = blockIdx.y * COUT;
+    const float4 *wg4 = reinterpret_cast<const float4 *>(p.w + (size_t)blockIdx.y * ((size_t)CIN * NTAPS * COUT));
 
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();                          // previous chunk fully consumed
@@ -181,12 +186,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
     // ---- epilogue ---------------------------------------------------------------
     const int j = lane & 31;
+    const int CT = p.cout_total;
     float s1[NT], t1[NT], s2[NT], t2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        s1[nt] = p.s1[nt * 32 + j]; t1[nt] = p.t1[nt * 32 + j];
-        s2[nt] = p.s2 ? p.s2[nt * 32 + j] : 1.f;
-        t2[nt] = p.t2 ? p.t2[nt * 32 + j] : 0.f;
+        s1[nt] = p.s1[cout_off + nt * 32 + j]; t1[nt] = p.t1[cout_off + nt * 32 + j];
+        s2[nt] = p.s2 ? p.s2[cout_off + nt * 32 + j] : 1.f;
+        t2[nt] = p.t2 ? p.t2[cout_off + nt * 32 + j] : 0.f;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             const int sp = pos_sp[q];
             if (sp < 0) continue;
             const int gw = pos_win[q];
-            float *o = p.out + (size_t)gw * p.out_win_stride + (size_t)sp * COUT + j;
-            const float *scp = p.sc ? p.sc + (size_t)gw * p.sc_win_stride + (size_t)sp * COUT + j : nullptr;
+            float *o = p.out + (size_t)gw * p.out_win_stride + (size_t)sp * CT + cout_off + j;
+            const float *scp = p.sc ? p.sc + (size_t)gw * p.sc_win_stride + (size_t)sp * CT + cout_off + j : nullptr;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float v = sigmoidf_(acc[mt][nt][e] * s1[nt] + t1[nt]);
@@ -208,7 +214,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------
 // Split-bf16 convolution ("bf16x6"): fp32-equivalent products on the bf16 MFMA pipe.
@@ -261,8 +266,13 @@ __host__ __device__ __forceinline__ void amt_split3(float x, unsigned short &h1,
     h3 = amt_f2bf(r2);
 }
 
-template <int KH, int KW, int CIN, int COUT>
-__global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const uint4 *__restrict__ w16) {
+// MASKED = true is the small-image form (whole H x W image of NWIN windows per workgroup):
+// the LDS tile holds only real positions plus one all-zero position, and every tap's A
+// fragment address is chosen per lane (in-bounds neighbour or the zero position), so the
+// "same" padding costs no LDS -- a 5x8 image with a 4x16 kernel would otherwise stage 4.6x its
+// size in halo zeros.  Layers are additionally split over blockIdx.y into COUT-wide slices.
+template <int KH, int KW, int CIN, int COUT, bool MASKED>
+__global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const uint4 *__restrict__ w16s) {
     // Geometry: 8 waves x one 32-position M-tile = 256 output positions per workgroup; the
     // contraction is walked in 16-channel chunks (one bf16 k-block per tap), so the staged
     // input tile is [pos][plane(3)][16 ch] bf16 = 112 B per position and TWO workgroups fit
@@ -283,10 +293,12 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
     char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][112 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int THin = p.TH + KH - 1, TWin = p.TW + KW - 1;
+    const int THin = MASKED ? p.TH : p.TH + KH - 1, TWin = MASKED ? p.TW : p.TW + KW - 1;
     // LDS row pitch (in positions) == TW (mod 16): consecutive flattened tile positions stay an
     // odd number (7) of 16-byte slots apart across the row wrap -> conflict-free b128 reads
-    const int RP = bx_row_pitch(p.TW, TWin);
+    const int RP = MASKED ? p.TW : bx_row_pitch(p.TW, TWin);
+    const int cout_off = blockIdx.y * COUT;                         // N-slice of this workgroup
+    const uint4 *w16 = w16s + (size_t)blockIdx.y * ((size_t)NCHUNK * NSLAB * SLAB_V4);
     int bid = blockIdx.x;
     const int tc = bid % p.tiles_w; bid /= p.tiles_w;
     const int tr = bid % p.tiles_h; bid /= p.tiles_h;
@@ -301,14 +313,16 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
         pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
         pos_win[q] = win0 + w_;
     }
-    int abase;
+    int abase, lr, lc;                                              // lane's LDS base and tile coords
     {
         int q = wid * 32 + (lane & 31);
         int w_ = q / ptile, rem = q - w_ * ptile;
         int r = rem / p.TW, c = rem - r * p.TW;
         if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
         abase = ((w_ * THin + r) * RP + c) * BX_PSTRIDE + (lane >> 5) * 16;
+        lr = r; lc = c;
     }
+    const int zero_off = p.NWIN * THin * RP * BX_PSTRIDE + (lane >> 5) * 16;   // MASKED: the zero position
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
                         const int pc = it >> 1;
                         const int wr = pc / TWin, ci = pc - wr * TWin;
                         const int w_ = wr / THin, ri = wr - w_ * THin;
-                        const int gr = r0 - PAD_T + ri, gc = c0 - PAD_L + ci, gw = win0 + w_;
+                        const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
                         dsto[u] = (wr * RP + ci) * BX_PSTRIDE + cg * 16;
                         if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
                             const float4 *src = reinterpret_cast<const float4 *>(
@@ -365,6 +379,9 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
                     }
                 }
             }
+        }
+        if (MASKED && tid < 7) {                                     // the all-zero position (112 B)
+            *reinterpret_cast<uint4 *>(in_lds + p.NWIN * THin * RP * BX_PSTRIDE + tid * 16) = make_uint4(0, 0, 0, 0);
         }
         // ---- K loop over weight slabs: 3 LDS buffers, global prefetch two slabs ahead ------
         //  step s: issue the loads of slab s+2 (registers), run slab s from LDS, then park
@@ -405,7 +422,14 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
                 for (int tt = 0; tt < TPS; ++tt) {
                     const int tap = s_ * TPS + tt;
                     const int dy = tap / KW, dx = tap - dy * KW;
-                    const char *ab = in_lds + abase + (dy * RP + dx) * BX_PSTRIDE;
+                    const char *ab;
+                    if constexpr (MASKED) {
+                        const int rr = lr + dy - PAD_T, cc = lc + dx - PAD_L;
+                        const bool inb = (unsigned)rr < (unsigned)p.H && (unsigned)cc < (unsigned)p.W;
+                        ab = in_lds + (inb ? abase + ((dy - PAD_T) * RP + (dx - PAD_L)) * BX_PSTRIDE : zero_off);
+                    } else {
+                        ab = in_lds + abase + (dy * RP + dx) * BX_PSTRIDE;
+                    }
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
                         a[tt][pl].u = *reinterpret_cast<const uint4 *>(ab + pl * 32);
@@ -449,7 +473,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
         }
     }
     // ---- epilogue (as in the f32 kernel, MT = 1) ---------------------------------------------
-    const int j = lane & 31;
+    const int j = cout_off + (lane & 31);
     float s1[NT], t1[NT], s2[NT], t2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -474,7 +498,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
         if (p.sc) {
 #pragma unroll
             for (int e8 = 0; e8 < EPB; ++e8) {
-                const float *scp = p.sc + (size_t)gwq[e8] * p.sc_win_stride + (size_t)max(spq[e8], 0) * COUT + j;
+                const float *scp = p.sc + (size_t)gwq[e8] * p.sc_win_stride + (size_t)max(spq[e8], 0) * p.cout_total + j;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) scv[e8][nt] = spq[e8] >= 0 ? scp[nt * 32] : 0.f;
             }
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
         for (int e8 = 0; e8 < EPB; ++e8) {
             const int e = half * EPB + e8;
             if (spq[e8] < 0) continue;
-            float *o = p.out + (size_t)gwq[e8] * p.out_win_stride + (size_t)spq[e8] * COUT + j;
+            float *o = p.out + (size_t)gwq[e8] * p.out_win_stride + (size_t)spq[e8] * p.cout_total + j;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float v = sigmoidf_(acc[nt][e] * s1[nt] + t1[nt]);
@@ -629,50 +653,61 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
 }
 
 // ---- Dense: C[M][N] = act(A[M][K] B[K][N] + bias[N]) on v_mfma_f32_32x32x2_f32 -----
-// 64x64 output tile per workgroup (4 waves, one 32x32 tile each), K in chunks of
-// 32 staged through LDS ([64][33] for A: conflict-free fragment reads).
+// M = windows is small (<= 512 per chunk) and N = 300, so the grid of output tiles is
+// tiny; to fill the chip a workgroup owns one 32x32 output tile and its 4 waves split K
+// four ways (wave-private LDS staging, [32][33] pitch: conflict-free fragment reads), then
+// the four partial tiles are summed through LDS in a fixed order (deterministic).
 #define DN_KC 32
 __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ A, int K,
                                                      const float *__restrict__ Bm,
                                                      const float *__restrict__ bias, int N,
                                                      float *__restrict__ Cm, int M, int act) {
-    __shared__ float as[64 * 33];
-    __shared__ float bs[DN_KC * 64];
+    __shared__ float as[4][32 * 33];
+    __shared__ float bs[4][DN_KC * 32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int mi = wid >> 1, ni = wid & 1;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kq = (((K + 3) / 4) + DN_KC - 1) / DN_KC * DN_KC;      // K range per wave, chunk aligned
+    const int kbeg = wid * kq, kend = min(K, kbeg + kq);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += DN_KC) {
+    float *aw = as[wid], *bw = bs[wid];
+    for (int k0 = 0; k0 < kq; k0 += DN_KC) {                         // same trip count in every wave
         __syncthreads();
-        for (int i = tid; i < 64 * DN_KC; i += 256) {
+        for (int i = lane; i < 32 * DN_KC; i += 64) {
             const int r = i / DN_KC, kk = i - r * DN_KC;
-            as[r * 33 + kk] = (m0 + r < M && k0 + kk < K) ? A[(size_t)(m0 + r) * K + k0 + kk] : 0.f;
+            const int k = kbeg + k0 + kk;
+            aw[r * 33 + kk] = (m0 + r < M && k < kend) ? A[(size_t)(m0 + r) * K + k] : 0.f;
         }
-        for (int i = tid; i < DN_KC * 64; i += 256) {
-            const int kk = i >> 6, c = i & 63;
-            bs[i] = (k0 + kk < K && n0 + c < N) ? Bm[(size_t)(k0 + kk) * N + n0 + c] : 0.f;
+        for (int i = lane; i < DN_KC * 32; i += 64) {
+            const int kk = i >> 5, c = i & 31;
+            const int k = kbeg + k0 + kk;
+            bw[i] = (k < kend && n0 + c < N) ? Bm[(size_t)k * N + n0 + c] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < DN_KC; kk += 2) {
-            const float a = as[(mi * 32 + (lane & 31)) * 33 + kk + (lane >> 5)];
-            const float bv = bs[(kk + (lane >> 5)) * 64 + ni * 32 + (lane & 31)];
+            const float a = aw[(lane & 31) * 33 + kk + (lane >> 5)];
+            const float bv = bw[(kk + (lane >> 5)) * 32 + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
         }
     }
-    const int n = n0 + ni * 32 + (lane & 31);
-    if (n < N) {
-        const float bv = bias[n];
+    __syncthreads();
+    // partial tiles -> LDS [wave][row][col(33)], then every thread sums 4 outputs
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (m < M) {
-                float v = acc[e] + bv;
-                if (act == 1) v = sigmoidf_(v);
-                Cm[(size_t)m * N + n] = v;
-            }
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        as[wid][row * 33 + (lane & 31)] = acc[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        const int m = m0 + row, n = n0 + col;
+        if (m < M && n < N) {
+            float v = ((as[0][row * 33 + col] + as[1][row * 33 + col]) +
+                       (as[2][row * 33 + col] + as[3][row * 33 + col])) + bias[n];
+            if (act == 1) v = sigmoidf_(v);
+            Cm[(size_t)m * N + n] = v;
         }
     }
 }
@@ -709,10 +744,13 @@ struct ConvOp {
     int pool_after = 0;        // 1 => maxpool (ph, pw) follows
     int TH = 0, TW = 0, NWIN = 1, MT = 2;
     size_t lds = 0;
+    int nslice = 1, cw = 0;    // output channels are computed in nslice slices of cw channels
     // split-bf16 variant (null when not built for this layer)
     uint4 *w16 = nullptr;
     int TH16 = 0, TW16 = 0, NWIN16 = 1;
     size_t lds16 = 0;
+    int nslice16 = 1, cw16 = 0;
+    bool masked16 = false;
     double eff32 = 0, eff16 = 0;
 };
 struct ProjOp {
@@ -768,7 +806,7 @@ static void choose_tile(ConvOp &c) {
         const int pcap = 128 * MT;
         auto consider = [&](int TH, int TW, int NWIN) {
             const size_t posin = (size_t)NWIN * (TH + c.kh - 1) * (TW + c.kw - 1);
-            const size_t lds = posin * RD_CSTRIDE * 4 + 2 * (size_t)RD_CC * c.cout * 4 + (size_t)pcap * 8;
+            const size_t lds = posin * RD_CSTRIDE * 4 + 2 * (size_t)RD_CC * c.cw * 4 + (size_t)pcap * 8;
             if (lds > 150 * 1024) return;
             const double tiles = (double)((c.H + TH - 1) / TH) * ((c.W + TW - 1) / TW) / NWIN;
             double eff = (double)c.H * c.W / (tiles * pcap);
@@ -792,13 +830,24 @@ static void choose_tile(ConvOp &c) {
 
 
 static size_t slab16_bytes(const ConvOp &c) {
-    const int NT = c.cout / 32, ntaps = c.kh * c.kw;
+    const int NT = c.cw16 / 32, ntaps = c.kh * c.kw;
     const int tps = (NT == 1 && ntaps % 2 == 0) ? 2 : 1;
     return (size_t)tps * 3 * NT * 64 * 16;
 }
 static void choose_tile16(ConvOp &c) {
     double best = -1;
     const int pcap = 256;
+    c.masked16 = false;
+    if (c.H * c.W <= 64) {
+        // small image: halo-free (masked) tile of whole images
+        const int nw = pcap / (c.H * c.W);
+        const size_t lds = ((size_t)nw * c.H * c.W + 1) * BX_PSTRIDE + 3 * slab16_bytes(c) + (size_t)pcap * 8;
+        if (lds <= 79 * 1024) {
+            c.masked16 = true; c.TH16 = c.H; c.TW16 = c.W; c.NWIN16 = nw; c.lds16 = lds;
+            c.eff16 = (double)nw * c.H * c.W / pcap;
+            return;
+        }
+    }
     auto consider = [&](int TH, int TW, int NWIN) {
         const size_t posin = (size_t)NWIN * (TH + c.kh - 1) * bx_row_pitch(TW, TW + c.kw - 1);
         const size_t lds = posin * BX_PSTRIDE + 3 * slab16_bytes(c) + (size_t)pcap * 8;
@@ -819,9 +868,9 @@ static void choose_tile16(ConvOp &c) {
     }
 }
 
-template <int KH, int KW, int CIN, int COUT>
+template <int KH, int KW, int CIN, int COUT, bool MASKED>
 static int launch_conv16_t(const ConvOp &c, ConvParams p, hipStream_t st) {
-    auto kern = conv_bf16x6_kernel<KH, KW, CIN, COUT>;
+    auto kern = conv_bf16x6_kernel<KH, KW, CIN, COUT, MASKED>;
     static bool attr_set = false;
     if (!attr_set) {
         AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -832,19 +881,23 @@ static int launch_conv16_t(const ConvOp &c, ConvParams p, hipStream_t st) {
     p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
-    kern<<<grid, 512, c.lds16, st>>>(p, c.w16);
+    kern<<<dim3(grid, c.nslice16), 512, c.lds16, st>>>(p, c.w16);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 template <int KH, int KW>
 static int launch_conv16_k(const ConvOp &c, const ConvParams &p, hipStream_t st) {
-    if (c.cin == 32 && c.cout == 32) return launch_conv16_t<KH, KW, 32, 32>(c, p, st);
-    if (c.cin == 32 && c.cout == 64) return launch_conv16_t<KH, KW, 32, 64>(c, p, st);
-    if (c.cin == 64 && c.cout == 64) return launch_conv16_t<KH, KW, 64, 64>(c, p, st);
+#define BX_CASE(CI, CO)                                                              \
+    if (c.cin == CI && c.cw16 == CO)                                                 \
+        return c.masked16 ? launch_conv16_t<KH, KW, CI, CO, true>(c, p, st)          \
+                          : launch_conv16_t<KH, KW, CI, CO, false>(c, p, st);
+    BX_CASE(32, 32) BX_CASE(32, 64) BX_CASE(64, 64) BX_CASE(128, 64)
+#undef BX_CASE
     return AMT_E_UNSUPPORTED;
 }
 static bool conv16_supported(const ConvOp &c) {
-    return (c.cin == 32 && c.cout == 32) || (c.cin == 32 && c.cout == 64) || (c.cin == 64 && c.cout == 64);
+    return (c.cin == 32 && c.cout == 32) || (c.cin == 32 && c.cout == 64) || (c.cin == 64 && c.cout == 64) ||
+           (c.cin == 64 && c.cout == 128) || (c.cin == 128 && c.cout == 128);
 }
 static int launch_conv16(const ConvOp &c, const ConvParams &p, hipStream_t st) {
     if (c.kh == 4 && c.kw == 16) return launch_conv16_k<4, 16>(c, p, st);
@@ -864,7 +917,7 @@ static int launch_conv_t(const ConvOp &c, const ConvParams &p, hipStream_t st) {
     }
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
-    kern<<<grid, 256, c.lds, st>>>(p);
+    kern<<<dim3(grid, c.nslice), 256, c.lds, st>>>(p);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
@@ -872,10 +925,11 @@ static int launch_conv_t(const ConvOp &c, const ConvParams &p, hipStream_t st) {
 template <int KH, int KW>
 static int launch_conv_k(const ConvOp &c, const ConvParams &p, hipStream_t st) {
 #define RD_CASE(CI, CO)                                                         \
-    if (c.cin == CI && c.cout == CO)                                            \
+    if (c.cin == CI && c.cw == CO)                                              \
         return c.MT == 2 ? launch_conv_t<KH, KW, CI, CO, 2>(c, p, st)           \
                          : launch_conv_t<KH, KW, CI, CO, 1>(c, p, st);
     RD_CASE(32, 32) RD_CASE(32, 64) RD_CASE(64, 64) RD_CASE(64, 128) RD_CASE(128, 128)
+    RD_CASE(64, 32) RD_CASE(128, 32)
 #undef RD_CASE
     return AMT_E_UNSUPPORTED;
 }
@@ -985,45 +1039,55 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     return AMT_E_UNSUPPORTED;
                 }
                 const int NT = fo / 32, nch = C / 32, ntap = kh * kw;
+                // small late-stage layers (few output positions per window) cannot fill 256 CUs with
+                // position tiles alone: compute them in 32-channel output slices (blockIdx.y)
+                c.nslice = (fo >= 128 && H * W <= 128) ? fo / 32 : 1;
+                c.cw = fo / c.nslice;
+                const int NTW = c.cw / 32;
                 std::vector<float> wa((size_t)ntap * C * fo);
-                // [cchunk][tap][c][j][nt]  <-  keras [tap][cin][cout], cout = 32*nt + j
-                for (int ch = 0; ch < nch; ++ch)
-                    for (int tap = 0; tap < ntap; ++tap)
-                        for (int cc = 0; cc < 32; ++cc)
-                            for (int j = 0; j < 32; ++j)
-                                for (int nt = 0; nt < NT; ++nt)
-                                    wa[((((size_t)ch * ntap + tap) * 32 + cc) * 32 + j) * NT + nt] =
-                                        kern[((size_t)tap * C + ch * 32 + cc) * fo + nt * 32 + j];
+                // [slice][cchunk][tap][c][j][ntw]  <-  keras [tap][cin][cout], cout = slice*cw + 32*ntw + j
+                for (int sl = 0; sl < c.nslice; ++sl)
+                    for (int ch = 0; ch < nch; ++ch)
+                        for (int tap = 0; tap < ntap; ++tap)
+                            for (int cc = 0; cc < 32; ++cc)
+                                for (int j = 0; j < 32; ++j)
+                                    for (int nt = 0; nt < NTW; ++nt)
+                                        wa[(((((size_t)sl * nch + ch) * ntap + tap) * 32 + cc) * 32 + j) * NTW + nt] =
+                                            kern[((size_t)tap * C + ch * 32 + cc) * fo + sl * c.cw + nt * 32 + j];
                 RD_TRY(upload(n, wa, &c.w));
                 choose_tile(c);
                 if (c.TH == 0) { amt_rdcnn_destroy(n); return AMT_E_UNSUPPORTED; }
                 if (conv16_supported(c)) {
+                    c.nslice16 = fo > 64 ? fo / 64 : 1;                // 128 couts run as two 64-wide slices
+                    c.cw16 = fo / c.nslice16;
                     choose_tile16(c);
                     // worth it only if 2.67x fewer matrix cycles survive the tile efficiency
                     if (c.TH16 > 0 && c.eff16 * 2.67 > c.eff32 * 1.15) {
-                        const int tps = (NT == 1 && ntap % 2 == 0) ? 2 : 1;
+                        const int NT16 = c.cw16 / 32;
+                        const int tps = (NT16 == 1 && ntap % 2 == 0) ? 2 : 1;
                         const int nslab = ntap / tps;
-                        // [chunk16][slab][tt][plane][nt][h][col][8] bf16
+                        // [slice][chunk16][slab][tt][plane][nt][h][col][8] bf16
                         const int nch16 = C / BX_CC;
                         std::vector<unsigned short> w16((size_t)nch16 * ntap * 3 * NT * 2 * 32 * 8);
-                        for (int ch = 0; ch < nch16; ++ch)
-                            for (int sl = 0; sl < nslab; ++sl)
-                                for (int tt = 0; tt < tps; ++tt)
-                                    for (int nt = 0; nt < NT; ++nt)
-                                        for (int h = 0; h < 2; ++h)
-                                            for (int col = 0; col < 32; ++col)
-                                                for (int jj = 0; jj < 8; ++jj) {
-                                                    const int tap = sl * tps + tt;
-                                                    const int cin_i = ch * BX_CC + 8 * h + jj;
-                                                    const float wv = kern[((size_t)tap * C + cin_i) * fo + nt * 32 + col];
-                                                    unsigned short hh[3];
-                                                    amt_split3(wv, hh[0], hh[1], hh[2]);
-                                                    for (int pl = 0; pl < 3; ++pl) {
-                                                        const size_t idx =
-                                                            (((((((size_t)ch * nslab + sl) * tps + tt) * 3 + pl) * NT + nt) * 2 + h) * 32 + col) * 8 + jj;
-                                                        w16[idx] = hh[pl];
+                        for (int sl = 0; sl < c.nslice16; ++sl)
+                            for (int ch = 0; ch < nch16; ++ch)
+                                for (int sb = 0; sb < nslab; ++sb)
+                                    for (int tt = 0; tt < tps; ++tt)
+                                        for (int nt = 0; nt < NT16; ++nt)
+                                            for (int h = 0; h < 2; ++h)
+                                                for (int col = 0; col < 32; ++col)
+                                                    for (int jj = 0; jj < 8; ++jj) {
+                                                        const int tap = sb * tps + tt;
+                                                        const int cin_i = ch * BX_CC + 8 * h + jj;
+                                                        const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cw16 + nt * 32 + col];
+                                                        unsigned short hh[3];
+                                                        amt_split3(wv, hh[0], hh[1], hh[2]);
+                                                        for (int pl = 0; pl < 3; ++pl) {
+                                                            const size_t idx =
+                                                                ((((((((size_t)sl * nch16 + ch) * nslab + sb) * tps + tt) * 3 + pl) * NT16 + nt) * 2 + h) * 32 + col) * 8 + jj;
+                                                            w16[idx] = hh[pl];
+                                                        }
                                                     }
-                                                }
                         void *d16 = nullptr;
                         if (hipMalloc(&d16, w16.size() * 2) != hipSuccess) { amt_rdcnn_destroy(n); return AMT_E_NOMEM; }
                         n->allocs.push_back(static_cast<float *>(d16));
@@ -1236,7 +1300,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     ConvParams cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                   Bc, H, W, c.TH, c.TW, c.NWIN, (H + c.TH - 1) / c.TH,
-                                  (W + c.TW - 1) / c.TW};
+                                  (W + c.TW - 1) / c.TW, c.cout};
                     const int rc = (net->mode == 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
                 }
@@ -1258,9 +1322,9 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
             }
             flat_off += tw.out_h * tw.out_w * tw.out_c;
         }
-        dense_kernel<<<dim3((DU + 63) / 64, (Bc + 63) / 64), 256, 0, st>>>(
+        dense_kernel<<<dim3((DU + 31) / 32, (Bc + 31) / 32), 256, 0, st>>>(
             flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1);
-        dense_kernel<<<dim3((K + 63) / 64, (Bc + 63) / 64), 256, 0, st>>>(
+        dense_kernel<<<dim3((K + 31) / 32, (Bc + 31) / 32), 256, 0, st>>>(
             d1, DU, net->d2w, net->d2b, K, lg, Bc, 0);
         head_output_kernel<<<(Bc + 63) / 64, 64, 0, st>>>(lg, y + (size_t)b0 * K, Bc, K, d.out_lo, d.out_hi);
         if (logits)
