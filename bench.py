@@ -214,8 +214,17 @@ def main():
     sub_bytes = B * (2 * 4 * F * T + 4 * F * loop.bank_frames) if n_sub else 0
     hbm_ms = stft_ms + sub_ms
     hbm_gbs = (n_stft * stft_bytes + n_sub * sub_bytes) / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else 0.0
+    stft_traffic = None
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf))
+            stft_traffic = int((t['stft']['hbm_bytes_per_window_per_launch'] +
+                                (t['subtract']['hbm_bytes_per_window_per_launch'] if n_sub else 0)) * B)
+        except Exception:
+            stft_traffic = None
     roofline_stft = dict(bound='hbm', achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                         frac=round(hbm_gbs / HBM_PEAK_GBS, 4), traffic=None,
+                         frac=round(hbm_gbs / HBM_PEAK_GBS, 4), traffic=stft_traffic,
+                         algorithmic_bytes=int(stft_bytes + sub_bytes),
                          kernel='stft_mag_kernel<2048,phase> + subtract_kernel',
                          stft_gbs=round(n_stft * stft_bytes / (stft_ms * 1e-3) / 1e9, 1) if stft_ms else None,
                          subtract_gbs=round(n_sub * sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
