@@ -155,6 +155,8 @@ def test_cqt_slices(env):
         inc2, len2 = audio.cqt_table(sr, fmin, n_bins, bpo)
         assert np.array_equal(inc, inc2) and np.array_equal(length, len2)
         table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        # row 0: 3 frames tiled to 8 (compact path, duplicates); row 1: 8 consecutive frames;
+        # row 2: empty slice -> zero columns
         src = np.stack([ocqt.slice_C_frames(79, 10, 13, 8), ocqt.slice_C_frames(79, 30, 50, 8),
                         ocqt.slice_C_frames(79, 70, 70, 8)]).astype(np.int32)
         out = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src).cuda(), table,
@@ -163,6 +165,15 @@ def test_cqt_slices(env):
             ref = ocqt.cqt_frames(wave[i], src[i], inc, length, hop)
             assert np.abs(out[i] - ref).max() <= REL * max(ref.max(), 1e-6), (fmin_midi, i)
         assert np.all(out[2] == 0)                      # empty slice -> zero columns (t == 0)
+        # frames spread over the whole window (generic path) incl. a hole and window edges,
+        # and a compact set that hangs over both ends of the signal
+        src2 = np.array([[0, 20, 40, 60, -1, 5, 78, 33], [0, 1, 2, 3, 4, 5, 6, 7],
+                         [71, 72, 73, 74, 75, 76, 77, 78]], np.int32)
+        out2 = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src2).cuda(), table,
+                                n_bins, hop).cpu().numpy()
+        for i in range(3):
+            ref = ocqt.cqt_frames(wave[i], src2[i], inc, length, hop)
+            assert np.abs(out2[i] - ref).max() <= REL * max(ref.max(), 1e-6), (fmin_midi, i)
 
 
 @pytest.mark.parametrize('case', [
