@@ -711,7 +711,11 @@ class audio_complete:
         raise NotImplementedError('spectral_flatness is a render sanity check outside the hot path')
 
     def save(self, filename, flac=True):
-        raise NotImplementedError('file output is outside the hot path (SURVEY 8f row 3)')
+        """util_audio.py:520-527: the waveform as PCM-24 FLAC (the WAV branch is not provided)."""
+        if not flac:
+            raise NotImplementedError('only FLAC output is provided')
+        from . import flac as _flac
+        _flac.save_float(np.asarray(self.wf), filename, sr=self.sr, bps=24)
 
 
 def _amplitude_to_db(S, ref, amin=1e-5, top_db=80.0):

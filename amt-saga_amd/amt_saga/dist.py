@@ -28,15 +28,17 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # AMT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
+            backend = os.environ.get('AMT_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         if backend == 'nccl':
-            torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local))
+                                    device_id=torch.device('cuda', torch.cuda.current_device()))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, world, local
 
 
@@ -58,6 +60,8 @@ def gather_events(events, n_total=None):
         out = ev
     else:
         world = dist.get_world_size()
+        if dist.get_backend() != 'nccl':
+            ev = ev.cpu()                      # gloo collectives run on host tensors
         n = torch.tensor([ev.shape[0]], dtype=torch.int64, device=ev.device)
         counts = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(counts, n)

@@ -1,201 +1,9 @@
-"""Minimal FLAC decoder (from the public FLAC format specification) used ONLY to
-turn the reference's recorded fixtures (subtraction_demo/*.flac,
-short_window_demo/*/*.flac -- 44.1 kHz mono PCM-24, written by
-util_audio.audio_to_flac, util_audio.py:966-968) into .npz golden vectors.
+"""FLAC decoding for the fixture generators: the product's own reader
+(amt-saga_amd/amt_saga/flac.py).  Kept as a module so that
+gen_golden_from_flac.py reads `import flac_decode as fd`."""
+import os
+import sys
 
-Supports: mono/independent channels, CONSTANT / VERBATIM / FIXED / LPC
-subframes, Rice and Rice2 residual coding with escapes, wasted bits, all
-block-size / sample-size header codes.  No stereo decorrelation is needed for
-the fixtures but left/side, right/side and mid/side are handled for completeness.
-Returns integer PCM; the caller scales by 2**-(bps-1) like libsndfile does.
-"""
-import numpy as np
-
-
-class _Bits:
-    def __init__(self, data, pos_bytes):
-        self.data = data
-        self.pos = pos_bytes * 8
-        bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))
-        self.ones = np.flatnonzero(bits)
-
-    def read(self, n):
-        if n == 0:
-            return 0
-        p = self.pos
-        b0 = p >> 3
-        b1 = (p + n + 7) >> 3
-        v = int.from_bytes(self.data[b0:b1], 'big')
-        v >>= (b1 * 8 - (p + n))
-        self.pos = p + n
-        return v & ((1 << n) - 1)
-
-    def read_signed(self, n):
-        v = self.read(n)
-        if n and v >> (n - 1):
-            v -= 1 << n
-        return v
-
-    def unary(self):
-        i = np.searchsorted(self.ones, self.pos)
-        q = int(self.ones[i]) - self.pos
-        self.pos += q + 1
-        return q
-
-    def align(self):
-        self.pos = (self.pos + 7) & ~7
-
-
-def _residual(br, blocksize, order, out):
-    method = br.read(2)
-    pbits = 4 if method == 0 else 5
-    esc = (1 << pbits) - 1
-    porder = br.read(4)
-    nparts = 1 << porder
-    idx = order
-    for p in range(nparts):
-        n = (blocksize >> porder) - (order if p == 0 else 0)
-        k = br.read(pbits)
-        if k == esc:
-            nb = br.read(5)
-            for _ in range(n):
-                out[idx] = br.read_signed(nb)
-                idx += 1
-        else:
-            for _ in range(n):
-                q = br.unary()
-                v = (q << k) | br.read(k)
-                out[idx] = (v >> 1) ^ -(v & 1)
-                idx += 1
-
-
-_FIXED = {0: [], 1: [1], 2: [2, -1], 3: [3, -3, 1], 4: [4, -6, 4, -1]}
-
-
-def _subframe(br, blocksize, bps):
-    if br.read(1):
-        raise ValueError('subframe padding bit set')
-    typ = br.read(6)
-    wasted = 0
-    if br.read(1):
-        wasted = br.unary() + 1
-        bps -= wasted
-    out = [0] * blocksize
-    if typ == 0:
-        out = [br.read_signed(bps)] * blocksize
-    elif typ == 1:
-        out = [br.read_signed(bps) for _ in range(blocksize)]
-    elif 8 <= typ <= 12:
-        order = typ - 8
-        for i in range(order):
-            out[i] = br.read_signed(bps)
-        _residual(br, blocksize, order, out)
-        co = _FIXED[order]
-        for i in range(order, blocksize):
-            out[i] += sum(c * out[i - j - 1] for j, c in enumerate(co))
-    elif typ >= 32:
-        order = (typ & 31) + 1
-        for i in range(order):
-            out[i] = br.read_signed(bps)
-        prec = br.read(4) + 1
-        shift = br.read_signed(5)
-        co = [br.read_signed(prec) for _ in range(order)]
-        _residual(br, blocksize, order, out)
-        for i in range(order, blocksize):
-            s = 0
-            for j in range(order):
-                s += co[j] * out[i - j - 1]
-            out[i] += s >> shift
-    else:
-        raise ValueError('reserved subframe type %d' % typ)
-    if wasted:
-        out = [v << wasted for v in out]
-    return out
-
-
-def decode(path):
-    """Returns (pcm int64 [n_samples, channels], sample_rate, bits_per_sample)."""
-    data = open(path, 'rb').read()
-    if data[:4] != b'fLaC':
-        raise ValueError('not a FLAC file')
-    pos = 4
-    sr = ch = bps = total = None
-    while True:
-        hdr = data[pos]
-        last, btype = hdr >> 7, hdr & 0x7F
-        blen = int.from_bytes(data[pos + 1:pos + 4], 'big')
-        body = data[pos + 4:pos + 4 + blen]
-        if btype == 0:
-            v = int.from_bytes(body[10:18], 'big')
-            sr = v >> 44
-            ch = ((v >> 41) & 7) + 1
-            bps = ((v >> 36) & 31) + 1
-            total = v & ((1 << 36) - 1)
-        pos += 4 + blen
-        if last:
-            break
-    br = _Bits(data, pos)
-    chans = [[] for _ in range(ch)]
-    got = 0
-    while got < total:
-        sync = br.read(14)
-        if sync != 0x3FFE:
-            raise ValueError('lost sync at bit %d' % br.pos)
-        br.read(1)
-        br.read(1)                                   # blocking strategy
-        bs_code = br.read(4)
-        sr_code = br.read(4)
-        ca = br.read(4)
-        ss_code = br.read(3)
-        br.read(1)
-        first = br.read(8)                           # UTF-8 coded number
-        n_extra = 0
-        while first & (0x80 >> n_extra):
-            n_extra += 1
-        for _ in range(max(0, n_extra - 1)):
-            br.read(8)
-        if bs_code == 1:
-            bs = 192
-        elif 2 <= bs_code <= 5:
-            bs = 576 << (bs_code - 2)
-        elif bs_code == 6:
-            bs = br.read(8) + 1
-        elif bs_code == 7:
-            bs = br.read(16) + 1
-        else:
-            bs = 256 << (bs_code - 8)
-        if sr_code == 12:
-            br.read(8)
-        elif sr_code in (13, 14):
-            br.read(16)
-        br.read(8)                                   # CRC-8
-        fbps = {0: bps, 1: 8, 2: 12, 4: 16, 5: 20, 6: 24}[ss_code]
-        if ca < 8:
-            subs = [_subframe(br, bs, fbps) for _ in range(ca + 1)]
-        else:
-            side_first = ca == 9
-            b0 = fbps + (1 if side_first else 0)
-            b1 = fbps + (0 if side_first else 1)
-            a = np.array(_subframe(br, bs, b0), dtype=np.int64)
-            b = np.array(_subframe(br, bs, b1), dtype=np.int64)
-            if ca == 8:
-                subs = [a, a - b]
-            elif ca == 9:
-                subs = [a + b, b]
-            else:
-                mid = (a << 1) | (b & 1)
-                subs = [(mid + b) >> 1, (mid - b) >> 1]
-        br.align()
-        br.read(16)                                  # CRC-16
-        for c in range(ch):
-            chans[c].extend(subs[c])
-        got += bs
-    pcm = np.array(chans, dtype=np.int64).T[:total]
-    return pcm, sr, bps
-
-
-def load_float(path):
-    """libsndfile-style float read: pcm / 2**(bps-1); mono -> 1-D float64."""
-    pcm, sr, bps = decode(path)
-    y = pcm.astype(np.float64) / float(1 << (bps - 1))
-    return (y[:, 0] if y.shape[1] == 1 else y), sr
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(_ROOT, 'amt-saga_amd'))
+from amt_saga.flac import decode, load_float  # noqa: E402,F401
