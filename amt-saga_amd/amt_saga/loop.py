@@ -17,6 +17,9 @@ per launch:
     C_velocity = slice_C(..., bpt=2, nbins=36, lowest=pitch-10) / ref_C_foc   training.py:382-388
     velocity  = rint(VelocityClassifier(C_velocity))
     guess     = template bank[(program group, pitch)]         stand-in for render(), synth.py
+                (guess='render': one note of the decided duration synthesised per window and
+                 iteration by amt_synth_windows and STFT'd -- what the reference does per note,
+                 training.py:421-431 -- instead of the fixed-duration bank row)
     mag       = relu(mag - guess * ref_mag/ref_mag(guess)) at frame `onset`   training.py:449
 
 Everything numeric is a HIP kernel behind the C ABI; torch only holds the
@@ -39,13 +42,16 @@ EVENT_FIELDS = ('window', 'iter', 'pitch', 'program', 'velocity', 'onset_frame',
 
 class TranscriptionLoop:
     def __init__(self, params, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True,
-                 groups=(0,), ref_frames=8, seeds=None):
+                 groups=(0,), ref_frames=8, seeds=None, guess='bank'):
         self.p = params
         self.heads = tuple(heads)
         self.iters = int(iters)
         self.do_subtract = bool(subtract)
         self.groups = tuple(groups)
         self.ref_frames = int(ref_frames)
+        if guess not in ('bank', 'render'):
+            raise ValueError('Requested attribute does not exist')
+        self.guess = guess
         self.lib = _lib.load()
         # default seeds: synthetic timing_start / timing_end nets whose (nearly input-independent)
         # outputs satisfy onset < end, so the short-window features are not empty
@@ -87,6 +93,9 @@ class TranscriptionLoop:
         for i, g in enumerate(self.groups):
             remap[g] = i
         self.prog_group = to_dev(remap[synth.prog_group_table(p.instrument_classes)], torch.int32)
+        self.prog_preset = to_dev(synth.prog_group_table(p.instrument_classes), torch.int32)
+        self.bank_dur = 1.0
+        self.bank_len = int(round((self.bank_dur + synth.TAIL_SECONDS) * sr))
         if bank_waves is None:
             bank_waves = synth.guess_bank_waves(self.groups, p.pitch_low, p.pitch_high, sr=sr, device=dev)
         bank = AudioBatch(bank_waves, p.N, p.H).stft(with_phase=False)
@@ -196,7 +205,16 @@ class TranscriptionLoop:
                 ptr(program), ptr(pitch), ptr(onset), ptr(end), ptr(self.prog_group),
                 self.prog_group.shape[0], B, p.pitch_low, p.pitch_high - p.pitch_low + 1,
                 self.tail_frames, self.bank_frames, ptr(gidx), ptr(gfr), st))
-            b.subtract(self.bank_mag, self.bank_max, gidx, gfr, onset, normalize=True, relu=True)
+            if self.guess == 'bank':
+                b.subtract(self.bank_mag, self.bank_max, gidx, gfr, onset, normalize=True, relu=True)
+            else:
+                notes = empty((B, 1, 5))
+                _lib.check(self.lib.amt_guess_notes(
+                    ptr(program), ptr(pitch), ptr(velocity), ptr(onset), ptr(end), ptr(self.prog_preset),
+                    self.prog_preset.shape[0], B, p.H / p.sr, self.bank_dur, 100.0, ptr(notes), st))
+                gw = synth.render_windows_device(notes, self.bank_len, p.sr)
+                g = AudioBatch(gw, p.N, p.H).stft(with_phase=False)
+                b.subtract(g.mag, g.ref_max, None, gfr, onset, normalize=True, relu=True)
         _lib.check(self.lib.amt_pack_events(B, int(window0), int(it), ptr(pitch), ptr(program),
                                             ptr(velocity), ptr(onset), ptr(end), ptr(events[it]), st))
 

@@ -12,9 +12,12 @@ benchmark windows and (b) the guess-template bank the subtraction step reads.
     window scaling follows render() (:778-781):
         wf * (vel_max/128)**4 / max|wf|,  vel_max - 12 for a single note
 
-Input generation only -- not part of the timed hot path.  Runs in torch on the
-device it is given (CPU for tests, the GPU for the benchmark) with float64
-phase so both give the same samples to ~1e-7.
+Two implementations of the same definition:
+  * render_window(): torch float64 on the CPU -- the synth's specification, used by the
+    CPU tests and as the checker for the kernel;
+  * render_windows_device(): the HIP kernel amt_synth_windows (csrc/amt_synth.hip) --
+    what the benchmark, the guess bank and the loop's "render" guess mode run.  It raises
+    without a GPU like every other product path.
 """
 import numpy as np
 import torch
@@ -69,6 +72,9 @@ def render_window(notes, L, sr=44100, device='cpu'):
     t = torch.arange(L, dtype=torch.float64, device=device) / sr
     wf = torch.zeros(L, dtype=torch.float64, device=device)
     for (g, p, v, t0, d) in notes:
+        # note records are float32 (the [B, M, 5] tensor the kernel reads): onset and duration
+        # take their float32 values here too, so both implementations see the same note
+        t0, d = float(np.float32(t0)), float(np.float32(d))
         amp = (v / 128.0) ** 4          # fluidsynth-like loudness spread between notes
         wf = wf + amp * _note(t, g, p, t0, d, sr)
     vel_max = max(n[2] for n in notes)
@@ -78,6 +84,40 @@ def render_window(notes, L, sr=44100, device='cpu'):
     if float(peak) > 0:
         wf = wf * ((vel_max / 128.0) ** 4 / peak)
     return wf.to(torch.float32)
+
+
+def notes_tensor(notes, max_notes=None):
+    """list (per window) of note lists -> float32 [B, max_notes, 5]; unused slots pitch -1."""
+    mn = max_notes or max(len(n) for n in notes)
+    out = np.zeros((len(notes), mn, 5), dtype=np.float32)
+    out[:, :, 1] = -1.0
+    for i, ns in enumerate(notes):
+        for j, n in enumerate(ns):
+            out[i, j] = n
+    return out
+
+
+def render_windows_device(notes, L, sr=44100, out=None):
+    """HIP synthesiser.  notes: list of note lists, or a device float32 [B, M, 5] tensor
+    (rows {group, pitch, velocity, onset_s, dur_s}; pitch < 0 = unused).  Returns a device
+    float32 [B, L] tensor."""
+    from . import _lib
+    from .device import empty, ptr, stream_ptr, to_dev
+    lib = _lib.load()
+    nt = notes if isinstance(notes, torch.Tensor) else to_dev(notes_tensor(notes))
+    if nt.dim() == 2:
+        nt = nt[:, None, :]
+    assert nt.dtype == torch.float32 and nt.shape[-1] == 5 and nt.is_contiguous()
+    B, M = nt.shape[0], nt.shape[1]
+    wave = out if out is not None else empty((B, int(L)))
+    peak = empty((B,))
+    _lib.check(lib.amt_synth_windows(ptr(nt), M, B, int(L), float(sr), ptr(wave), wave.stride(0),
+                                     ptr(peak), stream_ptr()))
+    return wave
+
+
+def _on_gpu(device):
+    return torch.device(device).type == 'cuda'
 
 
 def random_notes(rng, n_notes, groups=(0,), max_onset=3.0):
@@ -93,13 +133,13 @@ def make_windows(B, L, seed, notes_per_window=(3, 3), groups=(0,), sr=44100, dev
                  max_onset=3.0):
     """[B, L] float32 tensor of synthetic windows + the note lists."""
     rng = np.random.default_rng(seed)
-    waves, notes = [], []
+    notes = []
     for _ in range(B):
         n = int(rng.integers(notes_per_window[0], notes_per_window[1] + 1))
-        ns = random_notes(rng, n, groups, max_onset)
-        notes.append(ns)
-        waves.append(render_window(ns, L, sr, device))
-    return torch.stack(waves), notes
+        notes.append(random_notes(rng, n, groups, max_onset))
+    if _on_gpu(device):
+        return render_windows_device(notes, L, sr), notes
+    return torch.stack([render_window(ns, L, sr, device) for ns in notes]), notes
 
 
 def guess_bank_waves(groups=(0,), pitch_lo=21, pitch_hi=108, dur=1.0, velocity=100, sr=44100,
@@ -107,8 +147,7 @@ def guess_bank_waves(groups=(0,), pitch_lo=21, pitch_hi=108, dur=1.0, velocity=1
     """One rendered single-note guess per (group, pitch): [G*n_pitch, L_g] float32,
     L_g = (dur + 1 s tail) * sr samples (the reference's guess = note + 1 s, :876)."""
     Lg = int(round((dur + TAIL_SECONDS) * sr))
-    out = []
-    for g in groups:
-        for p in range(pitch_lo, pitch_hi + 1):
-            out.append(render_window([(g, p, velocity, 0.0, dur)], Lg, sr, device))
-    return torch.stack(out)
+    notes = [[(g, p, velocity, 0.0, dur)] for g in groups for p in range(pitch_lo, pitch_hi + 1)]
+    if _on_gpu(device):
+        return render_windows_device(notes, Lg, sr)
+    return torch.stack([render_window(ns, Lg, sr, device) for ns in notes])

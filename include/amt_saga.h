@@ -184,6 +184,24 @@ int amt_pack_events(int n, int window0, int iter, const int32_t *pitch,
 int amt_affine_i32(const int32_t *x, int n, int mul, int add, int32_t *out, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * Guess synthesis (stand-in for note_sequence.render(), util_audio.py:758-786:
+ * fluidsynth + soundfont are not available).  Additive synth defined in
+ * amt_saga/synth.py; window scaling follows render() (:778-781).
+ * ------------------------------------------------------------------------ */
+/* notes [B][max_notes][5] f32 = {preset group 0..2, midi pitch (<0 = unused slot),
+ * velocity, onset s, duration s}; wave [B][wave_stride] f32 out (L samples);
+ * peak_scratch [B] f32 device scratch. */
+int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate,
+                      float *wave, size_t wave_stride, float *peak_scratch, void *stream);
+/* one guess note per window from the loop's integer decisions:
+ * {prog_group[program], pitch, velocity (or default), 0, min((end-onset)*frame_seconds, max_dur)}
+ * (training.py:421-424 builds the guessed note the same way, from the gold values) */
+int amt_guess_notes(const int32_t *program, const int32_t *pitch, const int32_t *velocity,
+                    const int32_t *onset, const int32_t *end, const int32_t *prog_group,
+                    int n_prog, int n, float frame_seconds, float max_dur,
+                    float default_velocity, float *notes, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * RDCNN forward (replaces res_net.predict, RDCNN.py:591-597, for the graph
  * built by RDCNN.py:176-233).
  * ------------------------------------------------------------------------ */

@@ -28,15 +28,18 @@ def rint_clamp(x, lo, hi):
 
 class LoopOracle:
     def __init__(self, params, heads, weights, iters=1, subtract=True, prog_group=None,
-                 bank_waves=None, dtype=np.float32):
+                 bank_waves=None, dtype=np.float32, guess_fn=None):
         """weights: dict head-name -> weight dict ('timing_start', 'timing_end',
-        'pitch', 'instrument', 'velocity'); bank_waves [G*n_pitch, Lg] float."""
+        'pitch', 'instrument', 'velocity'); bank_waves [G*n_pitch, Lg] float.
+        guess_fn(program, pitch, velocity, frames) -> waveform: the product's 'render'
+        guess mode (one rendered guess per decision, training.py:421-431) instead of the bank."""
         self.p = params
         self.heads = tuple(heads)
         self.w = weights
         self.iters = iters
         self.do_subtract = subtract
         self.dtype = dtype
+        self.guess_fn = guess_fn
         self.cfg = {k: orc.head_config(params, k) for k in
                     ('timing', 'pitch', 'instrument', 'velocity')}
         self.prog_group = prog_group if prog_group is not None else np.zeros(params.instrument_classes, np.int32)
@@ -98,11 +101,17 @@ class LoopOracle:
                 n_pitch = p.pitch_high - p.pitch_low + 1
                 pr = min(max(program, 0), p.instrument_classes - 1) if program >= 0 else 0
                 g = int(self.prog_group[pr]) * n_pitch + min(max(pitch - p.pitch_low, 0), n_pitch - 1)
-                gf = min(max(end - onset, 0) + self.tail_frames, self.bank_frames)
+                if self.guess_fn is not None:
+                    gw = np.asarray(self.guess_fn(pr, pitch, velocity, max(end - onset, 0)), np.float32)
+                    gmag = oa.magphase(oa.stft(gw, p.N, p.H))[0]
+                    gmax, gframes = gmag.max(), gmag.shape[1]
+                else:
+                    gmag, gmax, gframes = self.bank_mag[g], self.bank_max[g], self.bank_frames
+                gf = min(max(end - onset, 0) + self.tail_frames, gframes)
                 # audio_complete.subtract with a magnitude subtrahend (util_audio.py:240-259),
                 # offset given directly in frames
-                mag_sub = self.bank_mag[g][:, :gf].copy()
-                mag_sub *= ac.ref_mag / self.bank_max[g]
+                mag_sub = gmag[:, :gf].copy()
+                mag_sub *= ac.ref_mag / gmax
                 if mag_sub.shape[1] + onset > T:
                     mag_sub = mag_sub[:, :T - onset]
                 m = ac.mag

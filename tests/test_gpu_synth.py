@@ -1,0 +1,96 @@
+"""GPU: the HIP note synthesiser (amt_synth_windows) against its float64 CPU
+specification (amt_saga/synth.py:render_window), and the loop's 'render' guess
+mode (one synthesised guess per decision, training.py:421-431) against the
+oracle loop given the CPU synth as its guess function."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    from amt_saga import synth, loop, hyperparams
+    from oracle import loop as oloop
+    return dict(torch=torch, synth=synth, loop=loop, hp=hyperparams, oloop=oloop)
+
+
+def test_synth_kernel_vs_cpu_definition(env):
+    synth, torch = env['synth'], env['torch']
+    rng = np.random.default_rng(5)
+    L, sr = 3 * 44100 + 77, 44100
+    notes = [synth.random_notes(rng, n, groups=(0, 1, 2), max_onset=1.5) for n in (1, 1, 2, 3, 5)]
+    notes.append([(1, 108, 127, 0.0, 0.5)])             # top pitch: harmonics cut at Nyquist
+    notes.append([(0, 21, 5, 2.9, 2.0)])                # quiet, late note running out of the window
+    notes.append([(2, 60, 64, 0.25, 0.1), (2, 60, 64, 0.25, 0.1)])   # identical notes
+    got = synth.render_windows_device(notes, L, sr).cpu().numpy()
+    for i, ns in enumerate(notes):
+        want = synth.render_window(ns, L, sr).numpy()
+        peak = np.abs(want).max()
+        assert peak > 0
+        assert np.abs(got[i] - want).max() / peak < 2e-5, i
+        vmax = max(n[2] for n in ns)
+        vmax = max(1, vmax - 12) if len(ns) == 1 else vmax
+        assert abs(np.abs(got[i]).max() - (vmax / 128.0) ** 4) / (vmax / 128.0) ** 4 < 1e-5
+    # unused slots / all-silent window
+    nt = synth.notes_tensor([[(0, 60, 100, 4.0, 0.5)], []], max_notes=3)
+    w = synth.render_windows_device(torch.from_numpy(nt).cuda(), 4410, sr).cpu().numpy()
+    assert np.all(w == 0)
+    # deterministic
+    a = synth.render_windows_device(notes, L, sr)
+    assert torch.equal(a, synth.render_windows_device(notes, L, sr))
+
+
+def test_synth_argument_checks(env):
+    from amt_saga import _lib
+    lib = _lib.load()
+    assert lib.amt_synth_windows(None, 1, 1, 10, 44100.0, None, 10, None, None) == _lib.AMT_E_INVALID
+    torch = env['torch']
+    nt = torch.zeros(1, 1, 5, device='cuda')
+    w = torch.zeros(1, 8, device='cuda')
+    pk = torch.zeros(1, device='cuda')
+    assert lib.amt_synth_windows(nt.data_ptr(), 1, 1, 16, 44100.0, w.data_ptr(), 8, pk.data_ptr(),
+                                 None) == _lib.AMT_E_SHAPE
+
+
+@pytest.mark.parametrize('heads,iters,seeds', [
+    (('timing', 'pitch', 'velocity'), 2, None),
+    (('timing', 'pitch', 'instrument', 'velocity'), 2, {'timing_start': 108}),
+])
+def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
+    torch, synth = env['torch'], env['synth']
+    p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
+    groups = (0, 1, 2) if 'instrument' in heads else (0,)
+    lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, seeds=seeds,
+                                       guess='render').setup_device()
+    L = p.H * (p.timing_frames - 1)
+    B = 3
+    wave, _ = synth.make_windows(B, L, seed=22, notes_per_window=(1, 3), groups=groups,
+                                 max_onset=0.4, device='cuda')
+    events, b = lp.run(wave, window0=7)
+    ev = events.cpu().numpy()
+    table = synth.prog_group_table(p.instrument_classes)
+    Lg = lp.bank_len
+
+    def guess_fn(program, pitch, velocity, frames):
+        dur = min(float(np.float32(frames) * np.float32(p.H / p.sr)), 1.0)
+        vel = velocity if velocity > 0 else 100
+        return synth.render_window([(int(table[program]), pitch, vel, 0.0, dur)], Lg, p.sr).numpy()
+
+    orc = env['oloop'].LoopOracle(p, heads, {k: n.weights for k, n in lp.nets.items()}, iters=iters,
+                                  guess_fn=guess_fn)
+    F = p.N // 2 + 1
+    checked = 0
+    for i in range(B):
+        refs = {k: v[i].item() for k, v in lp.refs.items()}
+        orc.margins = []
+        ev_ref, mag_ref = orc.run_window(wave[i].cpu().numpy(), refs, 7 + i)
+        if orc.margins and min(orc.margins) < 1e-3:
+            continue
+        checked += 1
+        assert np.array_equal(ev[:, i, :], ev_ref), (ev[:, i, :], ev_ref)
+        mag = b.mag[i].cpu().numpy()[:, :F].T
+        assert np.abs(mag - mag_ref).max() / mag_ref.max() < 1e-4
+    assert checked >= 2
