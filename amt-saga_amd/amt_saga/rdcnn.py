@@ -256,7 +256,8 @@ class res_net:
         return float(self._lib.amt_rdcnn_flops_per_window(self._net))
 
     def set_mode(self, mode):
-        """0 = f32 MFMA convolutions, 1 = split-bf16 (f32-equivalent) convolutions."""
+        """0 = f32 MFMA convolutions, 1 = split-bf16 (6 bf16 MFMAs per product block),
+        2 = split-fp16 (3 f16 MFMAs per product block); all f32-equivalent."""
         self.mode = int(mode)
         if self._net is not None:
             _lib.check(self._lib.amt_rdcnn_set_mode(self._net, self.mode))

@@ -518,6 +518,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x6_kernel(ConvParams p, const
     }
 }
 
+#include "amt_conv_f16x3.h"
+
 // ---- first layer (Cin = 1): direct convolution on the VALU ---------------------
 // A workgroup walks row tiles of 256/COUT*4 output columns of one window row.  The
 // input rows (with the zero halo) and all weights sit in LDS; thread = (column
@@ -752,6 +754,14 @@ struct ConvOp {
     int nslice16 = 1, cw16 = 0;
     bool masked16 = false;
     double eff32 = 0, eff16 = 0;
+    // split-fp16 variant (null when not built for this layer); N-slicing as for split-bf16
+    uint4 *wh = nullptr;
+    int THh = 0, TWh = 0, NWINh = 1;
+    size_t ldsh = 0;
+    bool maskedh = false;
+    double effh = 0;
+    int sw = 0;                // weights scaled by 2^sw
+    float alpha = 0, beta = 1; // input bound = alpha * max|network input| + beta
 };
 struct ProjOp {
     int cin, cout, H, W, ph, pw, HO, WO;
@@ -778,7 +788,7 @@ struct amt_rdcnn {
     float *d1w = nullptr, *d1b = nullptr, *d2w = nullptr, *d2b = nullptr;
     int flat = 0;
     double flops = 0;
-    mutable int mode = 0;      // 0: f32 MFMA, 1: split-bf16 where built
+    mutable int mode = 0;      // 0: f32 MFMA, 1: split-bf16 where built, 2: split-fp16 where built
 };
 
 static int upload(amt_rdcnn *n, const std::vector<float> &h, float **out) {
@@ -906,6 +916,81 @@ static int launch_conv16(const ConvOp &c, const ConvParams &p, hipStream_t st) {
     return AMT_E_UNSUPPORTED;
 }
 
+
+// ---- split-fp16 variant: tile choice and launch ---------------------------------------------
+#define HX_SLAB_BYTES 4096
+#define HX_XCHG_BYTES (8 * 16 * 64 * 4)         // K-split partial-sum exchange (COUT = 32)
+static void choose_tile_h(ConvOp &c) {
+    double best = -1;
+    const int pcap = 256;
+    c.maskedh = false; c.THh = 0;
+    auto total = [&](size_t posbytes) {
+        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + 3 * (size_t)HX_SLAB_BYTES + (size_t)pcap * 8;
+    };
+    if (c.H * c.W <= 64) {
+        const int nw = pcap / (c.H * c.W);
+        const size_t lds = total(((size_t)nw * c.H * c.W + 1) * HX_PSTRIDE);
+        if (lds <= 79 * 1024) {
+            c.maskedh = true; c.THh = c.H; c.TWh = c.W; c.NWINh = nw; c.ldsh = lds;
+            c.effh = (double)nw * c.H * c.W / pcap;
+            return;
+        }
+    }
+    auto consider = [&](int TH, int TW, int NWIN) {
+        const size_t posin = (size_t)NWIN * (TH + c.kh - 1) * bx_row_pitch(TW, TW + c.kw - 1);
+        const size_t lds = total(posin * HX_PSTRIDE);
+        if (lds > 79 * 1024) return;                    // two workgroups per CU
+        const double tiles = (double)((c.H + TH - 1) / TH) * ((c.W + TW - 1) / TW) / NWIN;
+        const double eff = (double)c.H * c.W / (tiles * pcap);
+        if (eff > best + 1e-9) { best = eff; c.THh = TH; c.TWh = TW; c.NWINh = NWIN; c.ldsh = lds; c.effh = eff; }
+    };
+    if (c.H * c.W <= pcap)
+        for (int nw = pcap / (c.H * c.W); nw >= 1; --nw) consider(c.H, c.W, nw);
+    for (int TH = 1; TH <= c.H && TH <= pcap; ++TH) {
+        int TW = pcap / TH;
+        if (TW > c.W) TW = c.W;
+        if (TW >= 1) consider(TH, TW, 1);
+        const int nct = (c.W + TW - 1) / TW;
+        const int TW2 = (c.W + nct - 1) / nct;
+        if (TW2 >= 1 && TW2 <= TW) consider(TH, TW2, 1);
+    }
+}
+
+template <int KH, int KW, int CIN, int COUT, bool MASKED>
+static int launch_convh_t(const ConvOp &c, ConvParams p, const float *xmax, hipStream_t st) {
+    auto kern = conv_f16x3_kernel<KH, KW, CIN, COUT, MASKED>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        attr_set = true;
+    }
+    p.TH = c.THh; p.TW = c.TWh; p.NWIN = c.NWINh;
+    p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
+    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
+    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
+    HxScale hs{xmax, c.alpha, c.beta, c.sw};
+    kern<<<dim3(grid, c.nslice16), 512, c.ldsh, st>>>(p, c.wh, hs);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+template <int KH, int KW>
+static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
+#define HX_CASE(CI, CO)                                                                    \
+    if (c.cin == CI && c.cw16 == CO)                                                       \
+        return c.maskedh ? launch_convh_t<KH, KW, CI, CO, true>(c, p, xmax, st)            \
+                         : launch_convh_t<KH, KW, CI, CO, false>(c, p, xmax, st);
+    HX_CASE(32, 32) HX_CASE(32, 64) HX_CASE(64, 64) HX_CASE(128, 64)
+#undef HX_CASE
+    return AMT_E_UNSUPPORTED;
+}
+static int launch_convh(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
+    if (c.kh == 4 && c.kw == 16) return launch_convh_k<4, 16>(c, p, xmax, st);
+    if (c.kh == 4 && c.kw == 2) return launch_convh_k<4, 2>(c, p, xmax, st);
+    if (c.kh == 2 && c.kw == 2) return launch_convh_k<2, 2>(c, p, xmax, st);
+    return AMT_E_UNSUPPORTED;
+}
+
 template <int KH, int KW, int CIN, int COUT, int MT>
 static int launch_conv_t(const ConvOp &c, const ConvParams &p, hipStream_t st) {
     auto kern = conv_mfma_kernel<KH, KW, CIN, COUT, MT>;
@@ -1016,11 +1101,14 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
         tw.in_h = d.in_h[t]; tw.in_w = d.in_w[t]; tw.ph = d.pool_h[t]; tw.pw = d.pool_w[t];
         int H = tw.in_h, W = tw.in_w, C = 1, fo = 32;
         int p0H = H, p0W = W, p0C = 1;
+        // |activation| <= a * X + b with X = max |tower input| (split-fp16 operand scaling)
+        double cur_a = 1, cur_b = 0, p0_a = 1, p0_b = 0;
         tw.max_act = (size_t)H * W;
         const int kh = d.kh[t], kw = d.kw[t];
         for (int i = 1; i <= d.conv_layers; ++i) {
             ConvOp c;
             c.cin = C; c.cout = fo; c.H = H; c.W = W; c.kh = kh; c.kw = kw;
+            c.alpha = (float)(cur_a * (1.0 + 1e-6)); c.beta = (float)(cur_b * (1.0 + 1e-6));
             const float *kern = take((size_t)kh * kw * C * fo);
             const float *bias = take(fo);
             BN bn{take(fo), take(fo), take(fo), take(fo)};
@@ -1096,6 +1184,51 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         }
                         c.w16 = static_cast<uint4 *>(d16);
                     }
+                    // split-fp16 weights: [slice][chunk16][slab][tt][plane(2)][nt][h][col][8] f16, scaled 2^sw
+                    choose_tile_h(c);
+                    float wmax = 0.f;
+                    bool finite = std::isfinite(c.alpha) && std::isfinite(c.beta);
+                    for (size_t q = 0; q < (size_t)ntap * C * fo; ++q) {
+                        if (!std::isfinite(kern[q])) finite = false;
+                        wmax = std::max(wmax, fabsf(kern[q]));
+                    }
+                    if (c.THh > 0 && finite && wmax > 0.f) {
+                        int ew = 0;
+                        (void)frexpf(wmax, &ew);                          // wmax < 2^ew
+                        c.sw = 4 - ew;                                     // max |w| 2^sw in [8, 16)
+                        const float wscale = ldexpf(1.0f, c.sw);
+                        const int NT16 = c.cw16 / 32;
+                        const int tps = NT16 == 1 ? 2 : 1;
+                        const int nslab = ntap / tps;
+                        const int nch16 = C / BX_CC;
+                        std::vector<unsigned short> whv((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
+                        for (int sl = 0; sl < c.nslice16; ++sl)
+                            for (int ch = 0; ch < nch16; ++ch)
+                                for (int sb = 0; sb < nslab; ++sb)
+                                    for (int tt = 0; tt < tps; ++tt)
+                                        for (int nt = 0; nt < NT16; ++nt)
+                                            for (int h = 0; h < 2; ++h)
+                                                for (int col = 0; col < 32; ++col)
+                                                    for (int jj = 0; jj < 8; ++jj) {
+                                                        const int tap = sb * tps + tt;
+                                                        const int cin_i = ch * BX_CC + 8 * h + jj;
+                                                        const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cw16 + nt * 32 + col];
+                                                        unsigned short hh[2];
+                                                        amt_split_f16(wv * wscale, hh[0], hh[1]);
+                                                        for (int pl = 0; pl < 2; ++pl) {
+                                                            const size_t idx =
+                                                                ((((((((size_t)sl * nch16 + ch) * nslab + sb) * tps + tt) * 2 + pl) * NT16 + nt) * 2 + h) * 32 + col) * 8 + jj;
+                                                            whv[idx] = hh[pl];
+                                                        }
+                                                    }
+                        void *dh = nullptr;
+                        if (hipMalloc(&dh, whv.size() * 2) != hipSuccess) { amt_rdcnn_destroy(n); return AMT_E_NOMEM; }
+                        n->allocs.push_back(static_cast<float *>(dh));
+                        if (hipMemcpy(dh, whv.data(), whv.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                            amt_rdcnn_destroy(n); return AMT_E_HIP;
+                        }
+                        c.wh = static_cast<uint4 *>(dh);
+                    }
                 }
             }
             n->flops += 2.0 * H * W * (double)kh * kw * C * fo;
@@ -1120,13 +1253,30 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     n->flops += 2.0 * H * W * (double)p0C * C;
                     c.sc_proj = (int)tw.projs.size();
                     tw.projs.push_back(pr);
+                    // |proj| <= max_j(|s_j| sum_c |w_cj|) * bound(p0) + max_j |t_j|  (avg-pool keeps the bound)
+                    double g = 0, tmax = 0;
+                    for (int j = 0; j < C; ++j) {
+                        double l1 = 1.0;
+                        if (pk) { l1 = 0; for (int cc = 0; cc < p0C; ++cc) l1 += fabs((double)pk[(size_t)cc * C + j]); }
+                        g = std::max(g, l1 * fabs((double)ps[j]));
+                        tmax = std::max(tmax, fabs((double)pt[j]));
+                    }
+                    p0_a = g * p0_a; p0_b = g * p0_b + tmax;
                 }
                 BN rbn{take(C), take(C), take(C), take(C)};
                 std::vector<float> rs, rt;
                 fold_bn(rbn, C, nullptr, rs, rt);
                 RD_TRY(upload(n, rs, &c.s2));
                 RD_TRY(upload(n, rt, &c.t2));
+                {   // out = (sigmoid + shortcut) * s2 + t2
+                    double smax = 0, tmax = 0;
+                    for (int j = 0; j < C; ++j) { smax = std::max(smax, fabs((double)rs[j])); tmax = std::max(tmax, fabs((double)rt[j])); }
+                    cur_a = p0_a * smax; cur_b = (1.0 + p0_b) * smax + tmax;
+                    p0_a = cur_a; p0_b = cur_b;
+                }
                 p0H = H; p0W = W; p0C = C;
+            } else {
+                cur_a = 0; cur_b = 1;                   // a sigmoid output
             }
             if (d.pool_layer_frequency > 0 && i % d.pool_layer_frequency == 0) {
                 c.pool_after = 1;
@@ -1159,7 +1309,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net) { return net ? net->flops : 0.0; }
 
 int amt_rdcnn_set_mode(amt_rdcnn *net, int mode) {
-    if (!net || mode < 0 || mode > 1) return AMT_E_INVALID;
+    if (!net || mode < 0 || mode > 2) return AMT_E_INVALID;
     net->mode = mode;
     return AMT_OK;
 }
@@ -1213,7 +1363,7 @@ static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);
     ma = (ma + 3) & ~(size_t)3;
     return (size_t)Bc * (4 * ma + (size_t)((n->flat + 3) & ~3) + (size_t)((n->d.dense_units + 3) & ~3) +
-                         (size_t)((n->d.output_classes + 3) & ~3));
+                         (size_t)((n->d.output_classes + 3) & ~3)) + 8;
 }
 
 size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B) {
@@ -1246,10 +1396,16 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
         float *flatbuf = ws + (size_t)4 * Bc * ma;
         float *d1 = flatbuf + (size_t)Bc * ((flat + 3) & ~3);
         float *lg = d1 + (size_t)Bc * ((DU + 3) & ~3);
+        float *xmax = lg + (size_t)Bc * ((K + 3) & ~3);              // [n_towers] max |tower input|
         int flat_off = 0;
+        if (net->mode == 2) AMT_HIP_CHECK(hipMemsetAsync(xmax, 0, 8 * sizeof(float), st));
         for (int t = 0; t < d.n_towers; ++t) {
             const Tower &tw = net->towers[t];
             const float *cur = x[t] + (size_t)b0 * tw.in_h * tw.in_w;
+            if (net->mode == 2) {
+                const size_t nin = (size_t)Bc * tw.in_h * tw.in_w;
+                absmax_kernel<<<(unsigned)std::min<size_t>((nin + 1023) / 1024, 1024), 256, 0, st>>>(cur, nin, xmax + t);
+            }
             size_t cur_stride = (size_t)tw.in_h * tw.in_w;
             const float *p0 = cur; size_t p0_stride = cur_stride;
             int H = tw.in_h, W = tw.in_w;
@@ -1301,7 +1457,8 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                   Bc, H, W, c.TH, c.TW, c.NWIN, (H + c.TH - 1) / c.TH,
                                   (W + c.TW - 1) / c.TW, c.cout};
-                    const int rc = (net->mode == 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
+                    const int rc = (net->mode == 2 && c.wh) ? launch_convh(c, cp, xmax + t, st)
+                                   : (net->mode >= 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
                 }
                 if (net->prof_on) {

@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--windows', type=int, default=0, help='windows per GPU (default: the workload size)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1),
+    ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1, 2),
                     help='1 = split-bf16 convolutions (f32-equivalent, default), 0 = f32 MFMA')
     args = ap.parse_args()
 

@@ -24,8 +24,8 @@ def _inputs(shape, B, seed):
     return (rng.random((B,) + tuple(shape)) ** 2).astype(np.float32)
 
 
-def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1)):
-    """Both convolution arithmetics (f32 MFMA, split-bf16) against the oracle."""
+def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1, 2)):
+    """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16) against the oracle."""
     out = None
     for mode in modes:
         head.set_mode(mode)
@@ -115,13 +115,50 @@ def test_timing_head_n2048_batch_independent(env):
     assert np.array_equal(y[perm], y2)
     y3 = h.predict_device([x[:1].contiguous()]).cpu().numpy()
     assert np.array_equal(y[:1], y3)
-    # split-bf16 convolutions: same properties, and within 1e-4 of the f32-MFMA result
-    h.set_mode(1)
-    z = h.predict_device([x]).cpu().numpy()
-    z2 = h.predict_device([x[torch.from_numpy(perm).cuda()].contiguous()]).cpu().numpy()
-    assert np.array_equal(z[perm], z2)
-    assert np.abs(z - y).max() / np.abs(y).max() < 1e-4
+    # split-bf16 / split-fp16 convolutions: same properties, and within 1e-4 of the f32-MFMA result
+    for mode in (1, 2):
+        h.set_mode(mode)
+        z = h.predict_device([x]).cpu().numpy()
+        z2 = h.predict_device([x[torch.from_numpy(perm).cuda()].contiguous()]).cpu().numpy()
+        assert np.array_equal(z[perm], z2)
+        assert np.abs(z - y).max() / np.abs(y).max() < 1e-4
     h.set_mode(0)
+
+
+def test_split_fp16_operand_range(env):
+    """The split-fp16 convolutions scale their operands from a bound of each layer's input
+    (static BN bounds x the measured max |network input|): inputs far outside the f16 range
+    (1e6, 1e-6) and weights scaled by 2^+-20 must give the f32-MFMA result, not inf/0."""
+    torch = env['torch']
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].VelocityClassifier(p)
+    x0 = _inputs((36, 8), 4, 11)
+    for scale in (1e6, 1e-6, 1.0):
+        x = torch.from_numpy(x0 * np.float32(scale)).cuda()
+        h.set_mode(0)
+        y0, l0 = h.predict_device([x], return_logits=True)
+        h.set_mode(2)
+        y2, l2 = h.predict_device([x], return_logits=True)
+        assert bool(torch.isfinite(l2).all())
+        assert float((l2 - l0).abs().max()) / max(float(l0.abs().max()), 1.0) < 2e-5, scale
+    # a network whose conv kernels are huge / small, BN statistics rescaled to match (the same
+    # function up to the BN epsilon): same outputs in both modes
+    w = {k: v.copy() for k, v in h.weights.items()}
+    for i in range(2, 12):
+        sc = np.float32(2.0 ** (20 if i % 2 else -5))
+        w['t0/conv%d/kernel' % i] *= sc
+        w['t0/conv%d/bias' % i] *= sc
+        w['t0/bn%d/mean' % i] *= sc
+        w['t0/bn%d/var' % i] *= sc * sc
+    h2 = env['heads'].VelocityClassifier(p)
+    h2.set_weights(w)
+    x = torch.from_numpy(x0).cuda()
+    h2.set_mode(0)
+    l0 = h2.predict_device([x], return_logits=True)[1]
+    h2.set_mode(2)
+    l2 = h2.predict_device([x], return_logits=True)[1]
+    assert bool(torch.isfinite(l2).all())
+    assert float((l2 - l0).abs().max()) / max(float(l0.abs().max()), 1.0) < 2e-5
 
 
 def test_classify_contract(env):
