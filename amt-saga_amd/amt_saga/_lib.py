@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libamt_saga_hip.so')
+# AMT_LIB_PATH overrides the in-tree library (diagnostic builds, packaged installs)
+LIB_PATH = os.environ.get('AMT_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'lib', 'libamt_saga_hip.so')
 
 AMT_OK = 0
 AMT_E_INVALID, AMT_E_SHAPE, AMT_E_HIP, AMT_E_NOMEM, AMT_E_UNSUPPORTED, AMT_E_ATTRIB = \

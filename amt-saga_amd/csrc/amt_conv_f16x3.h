@@ -38,6 +38,11 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Diagnostic builds only (scripts/ablate_conv.sh): -DHX_ABLATE=<bits> removes one phase to price it.
+//   1 staging loads + split   2 epilogue   4 MFMAs   8 A-fragment LDS reads   16 B-fragment global loads
+#ifndef HX_ABLATE
+#define HX_ABLATE 0
+#endif
 #define HX_PSTRIDE 80                        // bytes per staged position: 2 planes x 16 ch x 2 B + 16 pad
 #define HX_LSCALE 2048.0f                    // 2^11
 #define HX_MINNORM 6.103515625e-05f          // 2^-14
@@ -89,8 +94,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
     constexpr int SLAB_V4 = TPS * 2 * NT * 64;                      // = 256 uint4 (4 KB)
     static_assert(SLAB_V4 == 256, "one uint4 per thread of the lower half");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [3][SLAB_V4]
-    int *pos_sp = reinterpret_cast<int *>(wbuf + 3 * SLAB_V4);      // [PCAP]
+    int *pos_sp = reinterpret_cast<int *>(smem);                    // [PCAP]
     int *pos_win = pos_sp + PCAP;
     char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][80 B]
 
@@ -144,10 +148,13 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) { hi[mt][e] = 0.f; lo[mt][e] = 0.f; }
 
+    if (MASKED && tid < 20) {                                        // the all-zero position (80 B), written once
+        reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
+    }
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
         // ---- stage + split the input tile (16 channels) ---------------------------------
-        {
+        if (!(HX_ABLATE & 1)) {
             const int nrow = p.NWIN * THin;
             const int items = nrow * TWin * 2;
             constexpr int MAXIT = MASKED ? 1 : 2;          // masked tiles are one pass of <= 512 items
@@ -192,65 +199,86 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
                 }
             }
         }
-        if (MASKED && tid < 5) {                                     // the all-zero position (80 B)
-            *reinterpret_cast<uint4 *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE + tid * 16) = make_uint4(0, 0, 0, 0);
-        }
-        // ---- K loop over weight slabs (see conv_bf16x6_kernel for the prefetch discipline) ---
-        if (tid < SLAB_V4) wbuf[tid] = w16[(size_t)(ch * NSLAB) * SLAB_V4 + tid];
-        u32x2 wpa, wpb;                                   // 512 threads x 8 B = one 4-KB slab
-        auto issue = [&](u32x2 &wp, int slab) {
-            const uint2 *ptr = reinterpret_cast<const uint2 *>(w16 + (size_t)(ch * NSLAB + slab) * SLAB_V4) + tid;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wp) : "v"(ptr) : "memory");
-        };
-        auto park = [&](u32x2 &wp, int slab) {
-            reinterpret_cast<u32x2 *>(wbuf + (slab % 3) * SLAB_V4)[tid] = wp;
-        };
-        if (NSLAB > 1) issue(wpa, 1);
+        // ---- K loop: no barriers.  A fragments come from the LDS tile; B fragments (this wave's
+        //  tap / N-tile of each 4-KB weight slab: two 1-KB planes) come straight from global
+        //  memory -- all eight waves of every workgroup walk the same 2 x 2 KB per step, so they
+        //  are L1/L2 hits -- prefetched TWO steps ahead into rotating register sets (one step
+        //  ahead left the L2 latency exposed: 30 % of the kernel, profiles/r01/ablation_f16x3.txt).  The loads are
+        //  inline asm so that the compiler neither sinks them to their use nor counts them; the
+        //  destination registers must never be spilled while in flight (checked by the build).
         __syncthreads();
-        auto step = [&](int s_, u32x2 &w_next, u32x2 &w_new) {
-            if (s_ + 2 < NSLAB) issue(w_new, s_ + 2);
-            const int tt = (NT == 1) ? role : 0;
-            const int nt = (NT == 1) ? 0 : role;
-            const uint4 *wb = wbuf + (s_ % 3) * SLAB_V4 + (tt * 2 * NT + nt) * 64 + lane;
-            union U { uint4 u; f16x8 v; };
-            U a[2][2], b[2];
-            const int tap = s_ * TPS + tt;
+        union U { uint4 u; f16x8 v; u32x4 r; };
+        U b0[2], b1[2], b2[2];                            // B of steps s, s+1, s+2 (rotating)
+        const int frag = ((NT == 1) ? role * 2 : role) * 64 + lane;       // [tt][plane][nt][lane]
+        const uint4 *wptr = w16 + (size_t)(ch * NSLAB) * SLAB_V4 + frag;
+        auto issue = [&](U (&bb)[2], const uint4 *ptr) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bb[0].r) : "v"(ptr) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(bb[1].r) : "v"(ptr), "n"(NT * 64 * 16) : "memory");
+        };
+        if (!(HX_ABLATE & 16)) {
+            issue(b0, wptr);
+            if (NSLAB > 1) issue(b1, wptr + SLAB_V4);
+            if (NSLAB > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // step s computes with `b` (landed), `bn` (step s+1) is in flight, `bnn` receives step s+2
+        auto step = [&](int s_, U (&b)[2], U (&bnn)[2]) {
+            if (!(HX_ABLATE & 16) && s_ + 2 < NSLAB) issue(bnn, wptr + (size_t)(s_ + 2) * SLAB_V4);
+            const int tap = s_ * TPS + ((NT == 1) ? role : 0);
             const int dy = tap / KW, dx = tap - dy * KW;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const char *ab;
+            auto a_ptr = [&](int mt) -> const char * {
                 if constexpr (MASKED) {
                     const int rr = (int)((lrc >> (16 * mt)) & 255u) + dy - PAD_T;
                     const int cc = (int)((lrc >> (16 * mt + 8)) & 255u) + dx - PAD_L;
                     const bool inb = (unsigned)rr < (unsigned)p.H && (unsigned)cc < (unsigned)p.W;
-                    ab = in_lds + (inb ? abase[mt] + ((dy - PAD_T) * RP + (dx - PAD_L)) * HX_PSTRIDE : zero_off);
+                    return in_lds + (inb ? abase[mt] + ((dy - PAD_T) * RP + (dx - PAD_L)) * HX_PSTRIDE : zero_off);
                 } else {
-                    ab = in_lds + abase[mt] + (dy * RP + dx) * HX_PSTRIDE;
+                    return in_lds + abase[mt] + (dy * RP + dx) * HX_PSTRIDE;
                 }
-                a[mt][0].u = *reinterpret_cast<const uint4 *>(ab);
-                a[mt][1].u = *reinterpret_cast<const uint4 *>(ab + 32);
-            }
-            b[0].u = wb[0];
-            b[1].u = wb[NT * 64];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1].v, b[0].v, lo[mt], 0, 0, 0);
-                hi[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0].v, b[0].v, hi[mt], 0, 0, 0);
-                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0].v, b[1].v, lo[mt], 0, 0, 0);
+            };
+            auto a_read = [&](U (&a)[2], const char *ab) {
+                if (!(HX_ABLATE & 8)) {
+                    a[0].u = *reinterpret_cast<const uint4 *>(ab);
+                    a[1].u = *reinterpret_cast<const uint4 *>(ab + 32);
+                } else {
+                    asm volatile("" : "=v"(a[0].r), "=v"(a[1].r) : "v"(ab));
+                }
+            };
+            auto mfma3 = [&](int mt, U (&a)[2]) {
+                if (HX_ABLATE & 4) { asm volatile("" :: "v"(a[0].r), "v"(a[1].r), "v"(b[0].r), "v"(b[1].r)); return; }
+                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1].v, b[0].v, lo[mt], 0, 0, 0);
+                hi[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[0].v, hi[mt], 0, 0, 0);
+                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[1].v, lo[mt], 0, 0, 0);
+            };
+            if constexpr (MASKED) {
+                // small-image form: one A register set, tile after tile (the third B set needs the room)
+                U a[2];
+                a_read(a, a_ptr(0));
+                mfma3(0, a);
+                __builtin_amdgcn_sched_barrier(0);
+                a_read(a, a_ptr(1));
+                mfma3(1, a);
+            } else {
+                U a0[2], a1[2];
+                a_read(a0, a_ptr(0));
+                a_read(a1, a_ptr(1));
+                mfma3(0, a0);
+                mfma3(1, a1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (s_ + 1 < NSLAB) {
-                if (s_ + 2 < NSLAB) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                park(w_next, s_ + 1);
-            }
-            __syncthreads();
+            // step s+1's two loads must have landed; step s+2's two may stay in flight
+            if (s_ + 2 < NSLAB) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
-        static_assert(NSLAB % 2 == 0, "slab loop is unrolled by two");
-        for (int s_ = 0; s_ < NSLAB; s_ += 2) {
-            step(s_, wpa, wpb);
-            step(s_ + 1, wpb, wpa);
+        constexpr int NMAIN = NSLAB - NSLAB % 3;
+#pragma unroll 1
+        for (int s_ = 0; s_ < NMAIN; s_ += 3) {
+            step(s_, b0, b2);
+            step(s_ + 1, b1, b0);
+            step(s_ + 2, b2, b1);
         }
+        if constexpr (NSLAB % 3 >= 1) step(NMAIN, b0, b2);
+        if constexpr (NSLAB % 3 == 2) step(NMAIN + 1, b1, b0);
     }
     // ---- combine the two accumulators; COUT = 32: add the other tap-half's partial sums --------
     f32x16 res[2];
@@ -280,6 +308,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         if (NT == 1 && mt != role) continue;
+        if (HX_ABLATE & 2) { if (res[mt][0] == 123.456f) p.out[tid] = res[mt][1]; continue; }
 #pragma unroll
         for (int half = 0; half < 16 / EPB; ++half) {
             int spq[EPB], gwq[EPB];

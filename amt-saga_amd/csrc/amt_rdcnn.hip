@@ -925,7 +925,7 @@ static void choose_tile_h(ConvOp &c) {
     const int pcap = 256;
     c.maskedh = false; c.THh = 0;
     auto total = [&](size_t posbytes) {
-        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + 3 * (size_t)HX_SLAB_BYTES + (size_t)pcap * 8;
+        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + (size_t)pcap * 8;
     };
     if (c.H * c.W <= 64) {
         const int nw = pcap / (c.H * c.W);

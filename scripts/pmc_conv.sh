@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/pmc_conv; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 rm -rf /tmp/pmc_sq
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
-  --output-format csv -d /tmp/pmc_sq -- python3 $R/scripts/conv_microbench.py timing 128 0,1 > $OUT/micro.log 2> $OUT/micro.err
+  --output-format csv -d /tmp/pmc_sq -- python3 $R/scripts/conv_microbench.py timing ${PMC_B:-128} ${PMC_MODES:-0,1} > $OUT/micro.log 2> $OUT/micro.err
 python3 - <<'PY' > $OUT/sq_summary.txt
 import csv, glob
 from collections import defaultdict
