@@ -29,8 +29,9 @@ from . import _lib
 from .device import empty, ptr, require_gpu, stream_ptr, to_dev
 
 
-# convolution arithmetic: 1 = split-bf16 (f32-equivalent, ~1.5x faster end to end), 0 = f32 MFMA
-DEFAULT_MODE = int(__import__('os').environ.get('AMT_CONV_MODE', '1'))
+# convolution arithmetic (all f32-equivalent): 2 = split-fp16 (3 f16 MFMAs per product block, default),
+# 1 = split-bf16 (6 bf16 MFMAs), 0 = f32 MFMA
+DEFAULT_MODE = int(__import__('os').environ.get('AMT_CONV_MODE', '2'))
 
 
 def _to_list(single):

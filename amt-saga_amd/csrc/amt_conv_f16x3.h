@@ -40,6 +40,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Diagnostic builds only (scripts/ablate_conv.sh): -DHX_ABLATE=<bits> removes one phase to price it.
 //   1 staging loads + split   2 epilogue   4 MFMAs   8 A-fragment LDS reads   16 B-fragment global loads
+//   32 split + LDS write of the staged values (loads kept)   64 three loads in flight per thread while staging
 #ifndef HX_ABLATE
 #define HX_ABLATE 0
 #endif
@@ -52,13 +53,19 @@ __host__ __device__ __forceinline__ unsigned short amt_f16_bits(_Float16 h) {
     __builtin_memcpy(&b, &h, 2);
     return b;
 }
-// x is already scaled.  Returns the two f16 bit patterns.
+// x is already scaled.  Returns the two f16 bit patterns.  FLUSH = true (host, weights): a term
+// below the f16 normal range is set to zero, so the result does not depend on how the MFMA treats
+// f16 subnormals (for h < 2^-14 the whole value then moves into l, which has 2^11 more range).
+// FLUSH = false (device, activations: 4 VALU ops fewer per staged element): if the matrix pipe
+// flushed a subnormal term the value error would be < 2^-14 in scaled units = 2^-27 of the
+// layer's activation bound -- not worth the instructions.
+template <bool FLUSH>
 __host__ __device__ __forceinline__ void amt_split_f16(float xs, unsigned short &hb, unsigned short &lb) {
     _Float16 h = (_Float16)xs;
-    if (!(__builtin_fabsf(xs) >= HX_MINNORM)) h = (_Float16)0.0f;
+    if (FLUSH && !(__builtin_fabsf(xs) >= HX_MINNORM)) h = (_Float16)0.0f;
     const float r = (xs - (float)h) * HX_LSCALE;
     _Float16 l = (_Float16)r;
-    if (!(__builtin_fabsf(r) >= HX_MINNORM)) l = (_Float16)0.0f;
+    if (FLUSH && !(__builtin_fabsf(r) >= HX_MINNORM)) l = (_Float16)0.0f;
     hb = amt_f16_bits(h);
     lb = amt_f16_bits(l);
 }
@@ -94,7 +101,14 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
     constexpr int SLAB_V4 = TPS * 2 * NT * 64;                      // = 256 uint4 (4 KB)
     static_assert(SLAB_V4 == 256, "one uint4 per thread of the lower half");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int *pos_sp = reinterpret_cast<int *>(smem);                    // [PCAP]
+    constexpr int GROUP = NSLAB >= 4 ? 4 : NSLAB;                   // steps per weight group
+    static_assert(NSLAB % GROUP == 0, "whole groups");
+    constexpr int NG = NSLAB / GROUP, NGT = NCHUNK * NG;            // groups per chunk / in all
+    constexpr int GV4 = GROUP * SLAB_V4;                            // uint4 per group (16 KB for 4 steps)
+    constexpr int WPT = GV4 / 512;                                  // uint4 per thread and group
+    static_assert(GV4 % 512 == 0, "whole uint4 per thread");
+    uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [2][GV4]
+    int *pos_sp = reinterpret_cast<int *>(wbuf + 2 * GV4);          // [PCAP]
     int *pos_win = pos_sp + PCAP;
     char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][80 B]
 
@@ -105,7 +119,13 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
     const int RP = MASKED ? p.TW : bx_row_pitch(p.TW, TWin);
     const int cout_off = blockIdx.y * COUT;
     const uint4 *w16 = w16s + (size_t)blockIdx.y * ((size_t)NCHUNK * NSLAB * SLAB_V4);
-    int bid = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD one contiguous run of
+    // tiles -- neighbours that share halo columns / rows then share that XCD's L2
+    int bid;
+    {
+        const int nx = gridDim.x, q8 = nx >> 3, r8 = nx & 7, xcd = blockIdx.x & 7;
+        bid = xcd * q8 + min(xcd, r8) + (blockIdx.x >> 3);
+    }
     const int tc = bid % p.tiles_w; bid /= p.tiles_w;
     const int tr = bid % p.tiles_h; bid /= p.tiles_h;
     const int win0 = bid * p.NWIN;
@@ -148,6 +168,21 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) { hi[mt][e] = 0.f; lo[mt][e] = 0.f; }
 
+    // weight groups: group 0 straight into LDS, group 1 into the prefetch registers
+    u32x4 wp[WPT];
+    auto issue = [&](int gg) {
+        const uint4 *src = w16 + (size_t)gg * GV4 + tid;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
+    };
+    if (!(HX_ABLATE & 16)) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
+        if (NGT > 1) issue(1);
+    }
     if (MASKED && tid < 20) {                                        // the all-zero position (80 B), written once
         reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
     }
@@ -157,7 +192,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
         if (!(HX_ABLATE & 1)) {
             const int nrow = p.NWIN * THin;
             const int items = nrow * TWin * 2;
-            constexpr int MAXIT = MASKED ? 1 : 2;          // masked tiles are one pass of <= 512 items
+            constexpr int MAXIT = MASKED ? 1 : ((HX_ABLATE & 64) ? 3 : 2);   // masked tiles are one pass of <= 512 items
             for (int it0 = 0; it0 < items; it0 += 512 * MAXIT) {
                 float4 v0[MAXIT], v1[MAXIT];
                 int dsto[MAXIT];
@@ -182,10 +217,11 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
 #pragma unroll
                 for (int u = 0; u < MAXIT; ++u) {
                     if (dsto[u] < 0) continue;
+                    if (HX_ABLATE & 32) { asm volatile("" :: "v"(v0[u].x), "v"(v0[u].w), "v"(v1[u].x), "v"(v1[u].w)); continue; }
                     const float v[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
                     unsigned short h[2][8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) amt_split_f16(v[e] * in_scale, h[0][e], h[1][e]);
+                    for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
                     char *dst = in_lds + dsto[u];
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
@@ -199,31 +235,19 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
                 }
             }
         }
-        // ---- K loop: no barriers.  A fragments come from the LDS tile; B fragments (this wave's
-        //  tap / N-tile of each 4-KB weight slab: two 1-KB planes) come straight from global
-        //  memory -- all eight waves of every workgroup walk the same 2 x 2 KB per step, so they
-        //  are L1/L2 hits -- prefetched TWO steps ahead into rotating register sets (one step
-        //  ahead left the L2 latency exposed: 30 % of the kernel, profiles/r01/ablation_f16x3.txt).  The loads are
-        //  inline asm so that the compiler neither sinks them to their use nor counts them; the
-        //  destination registers must never be spilled while in flight (checked by the build).
-        __syncthreads();
+        // ---- K loop.  Weights travel global -> registers -> LDS in GROUPS of 4 steps (16 KB),
+        //  double-buffered: one barrier per group (24 MFMAs per wave), the next group's loads are
+        //  issued a whole group ahead.  (Per-step slabs cost a barrier per 6 MFMAs; per-wave B
+        //  loads straight from global cost 30 % in L1 throughput: profiles/r01/ablation_f16x3.txt.)
+        //  The loads are inline asm so that the compiler neither sinks them to their use nor
+        //  counts them; their destination registers must never be spilled while in flight
+        //  (checked by the build).
         union U { uint4 u; f16x8 v; u32x4 r; };
-        U b0[2], b1[2], b2[2];                            // B of steps s, s+1, s+2 (rotating)
-        const int frag = ((NT == 1) ? role * 2 : role) * 64 + lane;       // [tt][plane][nt][lane]
-        const uint4 *wptr = w16 + (size_t)(ch * NSLAB) * SLAB_V4 + frag;
-        auto issue = [&](U (&bb)[2], const uint4 *ptr) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bb[0].r) : "v"(ptr) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(bb[1].r) : "v"(ptr), "n"(NT * 64 * 16) : "memory");
-        };
-        if (!(HX_ABLATE & 16)) {
-            issue(b0, wptr);
-            if (NSLAB > 1) issue(b1, wptr + SLAB_V4);
-            if (NSLAB > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        // step s computes with `b` (landed), `bn` (step s+1) is in flight, `bnn` receives step s+2
-        auto step = [&](int s_, U (&b)[2], U (&bnn)[2]) {
-            if (!(HX_ABLATE & 16) && s_ + 2 < NSLAB) issue(bnn, wptr + (size_t)(s_ + 2) * SLAB_V4);
+        const int fragoff = ((NT == 1) ? role * 2 : role) * 64 + lane;      // [tt][plane][nt][lane]
+        auto step = [&](int s_, const uint4 *wb) {
+            U b[2];
+            b[0].u = wb[0];
+            b[1].u = wb[NT * 64];
             const int tap = s_ * TPS + ((NT == 1) ? role : 0);
             const int dy = tap / KW, dx = tap - dy * KW;
             auto a_ptr = [&](int mt) -> const char * {
@@ -250,35 +274,29 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
                 hi[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[0].v, hi[mt], 0, 0, 0);
                 lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[1].v, lo[mt], 0, 0, 0);
             };
-            if constexpr (MASKED) {
-                // small-image form: one A register set, tile after tile (the third B set needs the room)
-                U a[2];
-                a_read(a, a_ptr(0));
-                mfma3(0, a);
-                __builtin_amdgcn_sched_barrier(0);
-                a_read(a, a_ptr(1));
-                mfma3(1, a);
-            } else {
-                U a0[2], a1[2];
-                a_read(a0, a_ptr(0));
-                a_read(a1, a_ptr(1));
-                mfma3(0, a0);
-                mfma3(1, a1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // step s+1's two loads must have landed; step s+2's two may stay in flight
-            if (s_ + 2 < NSLAB) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            U a0[2], a1[2];
+            a_read(a0, a_ptr(0));
+            a_read(a1, a_ptr(1));
+            mfma3(0, a0);
+            mfma3(1, a1);
         };
-        constexpr int NMAIN = NSLAB - NSLAB % 3;
+        __syncthreads();                                   // tile staged (and group gg's weights parked)
 #pragma unroll 1
-        for (int s_ = 0; s_ < NMAIN; s_ += 3) {
-            step(s_, b0, b2);
-            step(s_ + 1, b1, b0);
-            step(s_ + 2, b2, b1);
+        for (int g = 0; g < NG; ++g) {
+            const int gg = ch * NG + g;
+            const uint4 *wb = wbuf + (gg & 1) * GV4 + fragoff;
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i) step(g * GROUP + i, wb + i * SLAB_V4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gg + 1 < NGT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // group gg+1 has landed in registers
+                u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + ((gg + 1) & 1) * GV4);
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) dst[tid + i * 512] = wp[i];
+                if (!(HX_ABLATE & 16) && gg + 2 < NGT) issue(gg + 2);
+            }
+            if (g + 1 < NG) __syncthreads();               // (the chunk loop's barriers cover the last group)
         }
-        if constexpr (NSLAB % 3 >= 1) step(NMAIN, b0, b2);
-        if constexpr (NSLAB % 3 == 2) step(NMAIN + 1, b1, b0);
     }
     // ---- combine the two accumulators; COUT = 32: add the other tap-half's partial sums --------
     f32x16 res[2];

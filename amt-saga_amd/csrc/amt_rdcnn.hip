@@ -924,8 +924,12 @@ static void choose_tile_h(ConvOp &c) {
     double best = -1;
     const int pcap = 256;
     c.maskedh = false; c.THh = 0;
+    // two weight-group buffers (a group = min(4, steps per chunk) steps of 4 KB)
+    const int NTh = c.cw16 / 32;
+    const int nsteps = c.kh * c.kw / (NTh == 1 ? 2 : 1);
+    const size_t wbytes = 2 * (size_t)std::min(4, nsteps) * HX_SLAB_BYTES;
     auto total = [&](size_t posbytes) {
-        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + (size_t)pcap * 8;
+        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + wbytes + (size_t)pcap * 8;
     };
     if (c.H * c.W <= 64) {
         const int nw = pcap / (c.H * c.W);
@@ -1214,7 +1218,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                                                         const int cin_i = ch * BX_CC + 8 * h + jj;
                                                         const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cw16 + nt * 32 + col];
                                                         unsigned short hh[2];
-                                                        amt_split_f16(wv * wscale, hh[0], hh[1]);
+                                                        amt_split_f16<true>(wv * wscale, hh[0], hh[1]);
                                                         for (int pl = 0; pl < 2; ++pl) {
                                                             const size_t idx =
                                                                 ((((((((size_t)sl * nch16 + ch) * nslab + sb) * tps + tt) * 2 + pl) * NT16 + nt) * 2 + h) * 32 + col) * 8 + jj;

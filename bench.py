@@ -184,26 +184,29 @@ def main():
     dom = by_class[dom_key]
     conv_ms_total = sum(a['ms'] for a in by_class.values())
     achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-    split = conv_mode == 1 and dom_key[2] <= 64
+    split = conv_mode >= 1 and dom_key[2] <= 64
+    nmf = 3 if conv_mode == 2 else 6                       # MFMAs per f32-equivalent product block
     # split-bf16: every algorithmic f32 MAC costs six bf16 MFMA MACs, so the MFMA roof for the
     # ALGORITHMIC flops of this kernel is the dense bf16 peak / 6
-    peak_tf = round(MFMA_BF16_PEAK_TF / 6.0, 1) if split else MFMA_F32_PEAK_TF
-    kname = ('conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)'
+    peak_tf = round(MFMA_BF16_PEAK_TF / nmf, 1) if split else MFMA_F32_PEAK_TF
+    kname = (('conv_f16x3_kernel<%d,%d,%d,%d> on %dx%d (3 x v_mfma_f32_32x32x16_f16 per f32 product block)'
+              if conv_mode == 2 else
+              'conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)')
              if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tf):
         try:
-            t = json.load(open(tf)).get('conv_bf16x6' if split else 'conv_mfma')
+            t = json.load(open(tf)).get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
             if t:
                 traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 512))
         except Exception:
             traffic = None
     roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=peak_tf, unit='TFLOP/s',
                     frac=round(achieved_tf / peak_tf, 4), traffic=traffic, kernel=kname,
-                    peak_note=('dense bf16 MFMA peak 2500 / 6 MFMAs per f32-equivalent product block'
+                    peak_note=('dense bf16/f16 MFMA peak 2500 / %d MFMAs per f32-equivalent product block' % nmf
                                if split else 'dense f32 MFMA peak'),
-                    executed_mfma_tflops=round(achieved_tf * (6 if split else 1), 1),
+                    executed_mfma_tflops=round(achieved_tf * (nmf if split else 1), 1),
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2))
@@ -243,7 +246,8 @@ def main():
             'value': round(value, 2), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if conv_mode == 0 else 'f32 (conv: split-bf16 x3 operands, f32 accumulate)',
+            'dtype': {0: 'f32', 1: 'f32 (conv: split-bf16 x3 operands, f32 accumulate)',
+                      2: 'f32 (conv: split-fp16 x2 operands, f32 accumulate)'}[conv_mode],
             'data': 'synthetic (additive-synth windows, seeded random-init weights)',
             'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
                        'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
