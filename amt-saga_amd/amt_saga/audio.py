@@ -80,6 +80,18 @@ def band_edges(n_rows, bands):
 # ======================================================================================
 # Batched, device-resident windows
 # ======================================================================================
+_DEV_TABLES = {}
+
+
+def _dev_table(key, build):
+    """Small constant index tables live on the device once: a pageable host-to-device copy
+    inside the loop would drain the stream on every call."""
+    t = _DEV_TABLES.get(key)
+    if t is None:
+        t = _DEV_TABLES[key] = to_dev(build(), torch.int32)
+    return t
+
+
 class AudioBatch:
     """B equally long windows processed together.  State: wave [B, L] f32,
     mag [B, T, ldf] f32, ph [B, T, ldf, 2] f32 (unit complex), ref_max [B] f32."""
@@ -174,8 +186,9 @@ class AudioBatch:
         (training.py:333-336)."""
         B, T = self.mag.shape[0], self.mag.shape[1]
         target = T if target_frames is None else int(target_frames)
-        edges = to_dev(band_edges(self.F, bands), torch.int32)
-        src = None if target == T else to_dev(resize_source_frames(T, target), torch.int32)
+        edges = _dev_table(('edges', self.F, bands), lambda: band_edges(self.F, bands))
+        src = None if target == T else _dev_table(('resize', T, target),
+                                                  lambda: resize_source_frames(T, target))
         out = empty((B, bands, target))
         _lib.check(self.lib.amt_compress_bands(
             ptr(self.mag), B, T, self.F, self.ldf, T * self.ldf, ptr(edges), bands, ptr(ref),

@@ -207,6 +207,111 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void istft_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// iSTFT, streaming form for hop = N/4 (librosa's default, every configuration of the path).
+// With N/hop = 4 and hop a multiple of the 256 threads, thread `tid` is the only one that
+// ever touches the segment samples = tid (mod 256), in every frame.  So the overlap-add needs
+// neither an LDS accumulator nor barriers of its own: each thread keeps a sliding window of
+// N/256 partial sums in registers; after frame slot s the hop/256 oldest are complete (no
+// later frame reaches them), get divided by the window sum-of-squares and are stored
+// (coalesced), and the window slides on.  LDS = FFT buffer + twiddles only (32 KB at N = 2048,
+// five workgroups per CU instead of two); frames are visited in increasing t, so the sums are
+// formed in the same order as in istft_kernel.
+// ---------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(AMT_FFT_THREADS) void istft_stream_kernel(
+    const float *__restrict__ mag, const float2 *__restrict__ phase, int T, int ldf,
+    size_t spec_stride, float *__restrict__ wave_out, size_t wave_stride, int Lout,
+    const float2 *__restrict__ tw_global, int center, int GH) {
+    static_assert(AMT_FFT_THREADS == 256 && N % 1024 == 0, "hop = N/4 must be a multiple of the block");
+    constexpr int HOP = N / 4, HPT = HOP / 256, NA = N / 256;
+    __shared__ float2 buf[N];
+    __shared__ float2 tw[N];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    for (int i = tid; i < N; i += AMT_FFT_THREADS) tw[i] = tw_global[i];
+    __syncthreads();
+    const int pad = center ? N / 2 : 0;
+    const int seg = GH * HOP;
+    const int p_lo = blockIdx.x * seg;
+    const int t_base = p_lo / HOP - 3;               // frame slot 0: the first frame reaching p_lo
+    const int nslots = GH + 3;
+    const float *mg = mag + (size_t)b * spec_stride;
+    const float2 *ph = phase ? phase + (size_t)b * spec_stride : nullptr;
+    float *out = wave_out + (size_t)b * wave_stride;
+    const float inv_n = 1.0f / (float)N;
+    float a[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a[i] = 0.f;
+
+    for (int s0 = 0; s0 < nslots; s0 += 2) {
+        const int t0 = t_base + s0;
+        const bool v0 = t0 >= 0 && t0 < T;
+        const bool v1 = (s0 + 1 < nslots) && (t0 + 1) >= 0 && (t0 + 1) < T;
+        if (v0 || v1) {
+            auto spec = [&](int t, int k) -> float2 {
+                float2 v;
+                if (ph) {
+                    const float m = mg[(size_t)t * ldf + k];
+                    const float2 q = ph[(size_t)t * ldf + k];
+                    v = make_float2(m * q.x, m * q.y);
+                } else {
+                    v = reinterpret_cast<const float2 *>(mg)[(size_t)t * ldf + k];
+                }
+                if (k == 0 || k == N / 2) v.y = 0.f;
+                return v;
+            };
+            auto load = [&](int n) -> float2 {
+                const bool mirror = n > N / 2;
+                const int k = mirror ? N - n : n;
+                float2 x1 = v0 ? spec(t0, k) : make_float2(0.f, 0.f);
+                float2 x2 = v1 ? spec(t0 + 1, k) : make_float2(0.f, 0.f);
+                if (mirror) { x1.y = -x1.y; x2.y = -x2.y; }
+                return make_float2(x1.x - x2.y, x1.y + x2.x);   // x1 + i*x2
+            };
+            fft_block<N, true>(buf, tw, load);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int s_ = s0 + f;
+            if (s_ >= nslots) break;
+            if (f == 0 ? v0 : v1) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int n = tid + 256 * i;
+                    const float w = 0.5f - 0.5f * tw[n].x;
+                    a[i] += (f == 0 ? buf[n].x : buf[n].y) * inv_n * w;
+                }
+            }
+            // the HPT oldest sums are complete: segment samples tid + 256 * (HPT * (s - 3) + e)
+#pragma unroll
+            for (int e = 0; e < HPT; ++e) {
+                const int j = HPT * (s_ - 3) + e;
+                if (j < 0 || j >= GH * HPT) continue;
+                const int p = p_lo + tid + 256 * j;
+                const int o = p - pad;
+                if (o < 0 || o >= Lout) continue;
+                int ta = (p - N + HOP) / HOP;
+                if (p - N + 1 <= 0) ta = 0;
+                int tb = p / HOP;
+                if (tb > T - 1) tb = T - 1;
+                float wss = 0.f;
+                for (int t = ta; t <= tb; ++t) {
+                    const float w = 0.5f - 0.5f * tw[p - t * HOP].x;
+                    wss += w * w;
+                }
+                float v = a[e];
+                if (wss > 1.17549435e-38f) v /= wss;
+                out[o] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NA - HPT; ++i) a[i] = a[i + HPT];
+#pragma unroll
+            for (int i = NA - HPT; i < NA; ++i) a[i] = 0.f;
+        }
+    }
+}
+
 // np.max over a window's [T][ldf] block --------------------------------------------
 __global__ __launch_bounds__(256) void window_max_kernel(const float *__restrict__ spec, int n,
                                                           size_t spec_stride,
@@ -260,6 +365,20 @@ static int launch_istft(const amt_stft_plan *plan, const float *mag, const float
                         int Lout, hipStream_t st) {
     constexpr int GH_HOP_MAX = 8 * 1024;            // floats of LDS accumulator (32 KB)
     const int hop = plan->hop;
+    if constexpr (N % 1024 == 0) {
+        if (hop * 4 == N) {
+            const int pad_ = plan->center ? N / 2 : 0;
+            int GHs = 32;
+            // keep >= ~2048 workgroups in flight when the batch is small
+            while (GHs > 4 && (size_t)((pad_ + Lout + GHs * hop - 1) / (GHs * hop)) * B < 2048) GHs >>= 1;
+            dim3 grid_s((pad_ + Lout + GHs * hop - 1) / (GHs * hop), B);
+            istft_stream_kernel<N><<<grid_s, AMT_FFT_THREADS, 0, st>>>(
+                mag, reinterpret_cast<const float2 *>(phase), T, ldf, spec_stride, out, wave_stride, Lout,
+                plan->tw_dev, plan->center, GHs);
+            AMT_LAUNCH_CHECK();
+            return AMT_OK;
+        }
+    }
     int GH = GH_HOP_MAX / hop;
     if (GH < 1) return AMT_E_UNSUPPORTED;
     if (GH > 16) GH = 16;

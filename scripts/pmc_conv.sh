@@ -1,22 +1,39 @@
 #!/bin/bash
-# ON THE GPU BOX: SQ counters of the conv kernels (one --pmc pass, no tracing domains)
+# ON THE GPU BOX: SQ counters of the conv kernels + GRBM_GUI_ACTIVE (separate --pmc passes, no
+# tracing domains) -> MFMA utilisation and effective clock per kernel.
+#   PMC_MODES=2 PMC_B=512 bash scripts/pmc_conv.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/pmc_conv; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-rm -rf /tmp/pmc_sq
+rm -rf /tmp/pmc_sq /tmp/pmc_grbm /tmp/pmc_kt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS \
   --output-format csv -d /tmp/pmc_sq -- python3 $R/scripts/conv_microbench.py timing ${PMC_B:-128} ${PMC_MODES:-0,1} > $OUT/micro.log 2> $OUT/micro.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_grbm -- python3 $R/scripts/conv_microbench.py timing ${PMC_B:-128} ${PMC_MODES:-0,1} > $OUT/micro_grbm.log 2> $OUT/micro_grbm.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pmc_kt -- python3 $R/scripts/conv_microbench.py timing ${PMC_B:-128} ${PMC_MODES:-0,1} > $OUT/micro_kt.log 2> $OUT/micro_kt.err
 python3 - <<'PY' > $OUT/sq_summary.txt
 import csv, glob
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(int)
-for f in glob.glob('/tmp/pmc_sq/**/*counter_collection.csv', recursive=True):
+for d in ('/tmp/pmc_sq', '/tmp/pmc_grbm'):
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name']
+            if 'conv_' not in k: continue
+            k = k[:60]
+            acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+            if r['Counter_Name'] == 'SQ_WAVE_CYCLES': n[k] += 1
+wall = defaultdict(float); nk = defaultdict(int)
+for f in glob.glob('/tmp/pmc_kt/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
+        k = r['Kernel_Name'][:60]
         if 'conv_' not in k: continue
-        k = k[:60]
-        acc[k][r['Counter_Name']] += float(r['Counter_Value'])
-        if r['Counter_Name'] == 'SQ_WAVE_CYCLES': n[k] += 1
+        wall[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-9; nk[k] += 1
+print('MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock = GRBM_GUI_ACTIVE / 8 / wall (un-profiled pass)')
 for k in acc:
+    a = acc[k]
     print(k, 'dispatches', n[k])
-    for c, v in sorted(acc[k].items()): print('   %-28s %.4g' % (c, v))
+    for c, v in sorted(a.items()): print('   %-28s %.4g' % (c, v))
+    if a.get('GRBM_GUI_ACTIVE') and a.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+        cyc = a['GRBM_GUI_ACTIVE'] / 8.0
+        print('   -> MFMA pipe busy %.1f %% of SIMD cycles' % (100.0 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc)))
+        if wall.get(k): print('   -> effective clock %.2f GHz (kernel-trace wall %.3f ms over %d dispatches)' % (cyc / wall[k] / 1e9, wall[k] * 1e3, nk[k]))
 PY
 cat $OUT/micro.log; cat $OUT/sq_summary.txt

@@ -77,7 +77,7 @@ def test_stft_edge_cases(mods):
         audio.AudioBatch(np.zeros((1, 3000), np.float32), 300)
 
 
-@pytest.mark.parametrize('n_fft,T', [(512, 37), (2048, 64), (2048, 65), (4096, 130)])
+@pytest.mark.parametrize('n_fft,T', [(512, 37), (1024, 33), (2048, 64), (2048, 65), (4096, 130)])
 def test_istft_vs_oracle_and_roundtrip(mods, n_fft, T):
     audio, oa = mods
     hop = n_fft // 4
@@ -100,6 +100,37 @@ def test_istft_vs_oracle_and_roundtrip(mods, n_fft, T):
         pc = (p[:, :Fb, 0] + 1j * p[:, :Fb, 1]).T
         ref = oa.istft(m * pc, hop)
         assert _relmax(y2[i], ref) < REL
+
+
+def test_istft_full_size_batch(mods):
+    """BASELINE-sized windows (516 frames) at a batch large enough for the 16-hop segments of the
+    streaming iSTFT kernel: STFT -> iSTFT is the identity for every window; a modified (inconsistent)
+    spectrogram matches the oracle's istft; a hop != N/4 plan (generic kernel) agrees as well."""
+    audio, oa = mods
+    import torch
+    n_fft, hop, T, B = 2048, 512, 516, 66
+    L = hop * (T - 1)
+    base = np.stack([_signal(L, 40 + s) for s in range(3)])
+    wave = np.concatenate([base] * (B // 3))
+    b = audio.AudioBatch(wave, n_fft).stft(True)
+    y = b.istft().cpu().numpy()
+    assert _relmax(y, wave) < REL
+    b.mag *= torch.linspace(1.0, 0.1, b.mag.shape[2], device=b.mag.device)
+    y2 = b.istft().cpu().numpy()
+    Fb = n_fft // 2 + 1
+    for i in (0, B - 1):
+        m = b.mag[i].cpu().numpy()[:, :Fb].T
+        p = b.ph[i].cpu().numpy()
+        pc = (p[:, :Fb, 0] + 1j * p[:, :Fb, 1]).T
+        assert _relmax(y2[i], oa.istft(m * pc, hop)) < REL
+    assert np.array_equal(y2[0], y2[3])                       # same window, other place in the batch
+    # hop = N/8: the generic gather kernel
+    hop8 = 256
+    L8 = hop8 * 80
+    w8 = np.stack([_signal(L8, 50 + s) for s in range(2)])
+    b8 = audio.AudioBatch(w8, n_fft, hop8).stft(True)
+    y8 = b8.istft().cpu().numpy()
+    assert _relmax(y8, w8) < REL
 
 
 def test_subtract_golden_bit_exact(mods, refvec):
