@@ -588,6 +588,96 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
     }
 }
 
+// ---- first layer on the matrix pipe (Cout = 32) ---------------------------------------------
+// GEMM view: M = output positions, N = 32 filters, K = KH*KW taps; v_mfma_f32_32x32x2_f32 (f32
+// in, f32 accumulate: the same k-ordered fmaf chain as conv1_kernel).  The whole [K][32] kernel
+// lives in K/2 B-fragment registers per lane; an A fragment is one ds_read_b32 of the
+// single-channel input tile (lane = position, lane half = the odd tap of a tap pair, i.e. the
+// next column).  A workgroup (4 waves) owns a TH x TW tile of <= 512 positions = <= 16 M-tiles,
+// wave w takes M-tiles w, w+4, ...; workgroups walk the tiles grid-stride.
+#define C1M_PCAP 512
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, int TW, int tiles_h,
+                                                          int tiles_w) {
+    constexpr int K = KH * KW, NK2 = K / 2;
+    static_assert(K % 2 == 0 && KW % 2 == 0, "tap pairs share a kernel row");
+    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RPW = TW + KW - 1, THin = TH + KH - 1;
+    int *pos_rc = reinterpret_cast<int *>(smem);            // [PCAP] r | c << 16 (tile-local)
+    int *pos_sp = pos_rc + C1M_PCAP;                         // [PCAP] global spatial index or -1
+    float *xt = reinterpret_cast<float *>(pos_sp + C1M_PCAP);   // [THin][RPW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PT = TH * TW, nmt = (PT + 31) >> 5;
+    for (int q = tid; q < C1M_PCAP; q += 256) {
+        const int r = q / TW, c = q - r * TW;
+        pos_rc[q] = q < PT ? (r | (c << 16)) : -1;
+    }
+    const int co = lane & 31;
+    float bq[NK2];
+#pragma unroll
+    for (int i = 0; i < NK2; ++i) bq[i] = p.w[(2 * i + (lane >> 5)) * 32 + co];
+    const float s1 = p.s1[co], t1 = p.t1[co];
+    const float s2 = p.s2 ? p.s2[co] : 1.f, t2 = p.t2 ? p.t2[co] : 0.f;
+    const long total = (long)p.B * tiles_h * tiles_w;
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int tc = (int)(tile % tiles_w);
+        const long rest = tile / tiles_w;
+        const int tr = (int)(rest % tiles_h);
+        const int b = (int)(rest / tiles_h);
+        const int r0 = tr * TH, c0 = tc * TW;
+        const float *x = p.in + (size_t)b * p.in_win_stride;
+        __syncthreads();                                     // previous tile consumed (pos_rc visible)
+        for (int i = tid; i < THin * RPW; i += 256) {
+            const int ri = i / RPW, ci = i - ri * RPW;
+            const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L;
+            xt[i] = (gr >= 0 && gr < p.H && gc >= 0 && gc < p.W) ? x[(size_t)gr * p.W + gc] : 0.f;
+        }
+        for (int q = tid; q < C1M_PCAP; q += 256) {
+            const int rc = pos_rc[q];
+            const int r = r0 + (rc & 0xFFFF), c = c0 + (rc >> 16);
+            pos_sp[q] = (rc >= 0 && r < p.H && c < p.W) ? r * p.W + c : -1;
+        }
+        __syncthreads();
+        for (int mt = wid; mt < nmt; mt += 4) {
+            const int rc = pos_rc[mt * 32 + (lane & 31)];
+            const int abase = rc >= 0 ? (rc & 0xFFFF) * RPW + (rc >> 16) + (lane >> 5) : (lane >> 5);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NK2; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int dy = (2 * i) / KW, dx = (2 * i) % KW;
+                const float a = xt[abase + dy * RPW + dx];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[i], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int sp = pos_sp[mt * 32 + row];
+                if (sp < 0) continue;
+                float v = sigmoidf_(acc[e] * s1 + t1);
+                if (p.sc) v = (v + p.sc[(size_t)b * p.sc_win_stride + (size_t)sp * 32 + co]) * s2 + t2;
+                p.out[(size_t)b * p.out_win_stride + (size_t)sp * 32 + co] = v;
+            }
+        }
+    }
+}
+// tile of <= 512 positions that needs the fewest 32-position M-tiles over the image
+static void choose_tile1(int H, int W, int *TH_, int *TW_) {
+    long best = -1;
+    for (int TH = 1; TH <= H && TH <= C1M_PCAP; ++TH) {
+        int TWmax = std::min(W, C1M_PCAP / TH);
+        for (int TW = std::max(1, TWmax - 40); TW <= TWmax; ++TW) {
+            const long tiles = (long)((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+            const long cost = tiles * ((TH * TW + 31) / 32);
+            if (best < 0 || cost < best) { best = cost; *TH_ = TH; *TW_ = TW; }
+        }
+    }
+}
+
 // ---- shortcut projection: BN(avgpool(conv1x1(x)))  (RDCNN.py:328-334) -----------
 // The 1x1 convolution and the average pool commute; pooling first cuts the
 // contraction work by the pool area.  A workgroup owns <= 64 output columns of one
@@ -658,18 +748,25 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
 // M = windows is small (<= 512 per chunk) and N = 300, so the grid of output tiles is
 // tiny; to fill the chip a workgroup owns one 32x32 output tile and its 4 waves split K
 // four ways (wave-private LDS staging, [32][33] pitch: conflict-free fragment reads), then
-// the four partial tiles are summed through LDS in a fixed order (deterministic).
+// the four partial tiles are summed through LDS in a fixed order (deterministic).  A long
+// contraction (the 5120-wide flatten of the timing head) is additionally split over
+// gridDim.z workgroups that write partial tiles; dense_reduce_kernel adds them in z order.
 #define DN_KC 32
+#define DN_KSPLIT 8
 __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ A, int K,
                                                      const float *__restrict__ Bm,
                                                      const float *__restrict__ bias, int N,
-                                                     float *__restrict__ Cm, int M, int act) {
+                                                     float *__restrict__ Cm, int M, int act,
+                                                     float *__restrict__ part) {
     __shared__ float as[4][32 * 33];
     __shared__ float bs[4][DN_KC * 32];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const int kq = (((K + 3) / 4) + DN_KC - 1) / DN_KC * DN_KC;      // K range per wave, chunk aligned
-    const int kbeg = wid * kq, kend = min(K, kbeg + kq);
+    const int KS = gridDim.z;
+    const int Kz = ((K + KS - 1) / KS + 4 * DN_KC - 1) / (4 * DN_KC) * (4 * DN_KC);   // K range per workgroup
+    const int kz1 = min(K, (int)(blockIdx.z + 1) * Kz);
+    const int kq = Kz / 4;                                           // K range per wave, chunk aligned
+    const int kbeg = blockIdx.z * Kz + wid * kq, kend = min(kz1, kbeg + kq);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -707,11 +804,23 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ A,
         const int m = m0 + row, n = n0 + col;
         if (m < M && n < N) {
             float v = ((as[0][row * 33 + col] + as[1][row * 33 + col]) +
-                       (as[2][row * 33 + col] + as[3][row * 33 + col])) + bias[n];
+                       (as[2][row * 33 + col] + as[3][row * 33 + col]));
+            if (part) { part[((size_t)blockIdx.z * M + m) * N + n] = v; continue; }
+            v += bias[n];
             if (act == 1) v = sigmoidf_(v);
             Cm[(size_t)m * N + n] = v;
         }
     }
+}
+__global__ void dense_reduce_kernel(const float *__restrict__ part, int KS, const float *__restrict__ bias,
+                                    int N, float *__restrict__ Cm, int M, int act) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float v = part[i];
+    for (int z = 1; z < KS; ++z) v += part[(size_t)z * M * N + i];
+    v += bias[i % N];
+    if (act == 1) v = sigmoidf_(v);
+    Cm[i] = v;
 }
 
 // ---- output activation: softmax (K > 1) or sigmoid + range scaling (K == 1) -------
@@ -1446,7 +1555,20 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     }
                     AMT_HIP_CHECK(hipEventRecord(pe0, st));
                 }
-                if (c.cin == 1) {
+                if (c.cin == 1 && c.cout == 32 && conv_supported(c.kh, c.kw)) {
+                    Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
+                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
+                                   Bc, H, W, c.kh, c.kw, c.cout};
+                    int TH1 = 1, TW1 = 1;
+                    choose_tile1(H, W, &TH1, &TW1);
+                    const int th = (H + TH1 - 1) / TH1, twn = (W + TW1 - 1) / TW1;
+                    const size_t lds = (size_t)2 * C1M_PCAP * 4 + (size_t)(TH1 + c.kh - 1) * (TW1 + c.kw - 1) * 4;
+                    const unsigned grid = (unsigned)std::min<size_t>((size_t)Bc * th * twn, 256 * 8);
+                    if (c.kh == 4 && c.kw == 16) conv1_mfma_kernel<4, 16><<<grid, 256, lds, st>>>(cp, TH1, TW1, th, twn);
+                    else if (c.kh == 4 && c.kw == 2) conv1_mfma_kernel<4, 2><<<grid, 256, lds, st>>>(cp, TH1, TW1, th, twn);
+                    else conv1_mfma_kernel<2, 2><<<grid, 256, lds, st>>>(cp, TH1, TW1, th, twn);
+                    AMT_LAUNCH_CHECK();
+                } else if (c.cin == 1) {
                     Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                    c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                    Bc, H, W, c.kh, c.kw, c.cout};
@@ -1483,10 +1605,18 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
             }
             flat_off += tw.out_h * tw.out_w * tw.out_c;
         }
-        dense_kernel<<<dim3((DU + 31) / 32, (Bc + 31) / 32), 256, 0, st>>>(
-            flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1);
+        if (flat >= 2048 && ma >= (size_t)DN_KSPLIT * DU) {
+            float *dpart = buf[0];                         // the activation buffers are dead by now
+            dense_kernel<<<dim3((DU + 31) / 32, (Bc + 31) / 32, DN_KSPLIT), 256, 0, st>>>(
+                flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1, dpart);
+            dense_reduce_kernel<<<(unsigned)(((size_t)Bc * DU + 255) / 256), 256, 0, st>>>(
+                dpart, DN_KSPLIT, net->d1b, DU, d1, Bc, 1);
+        } else {
+            dense_kernel<<<dim3((DU + 31) / 32, (Bc + 31) / 32), 256, 0, st>>>(
+                flatbuf, flat, net->d1w, net->d1b, DU, d1, Bc, 1, nullptr);
+        }
         dense_kernel<<<dim3((K + 31) / 32, (Bc + 31) / 32), 256, 0, st>>>(
-            d1, DU, net->d2w, net->d2b, K, lg, Bc, 0);
+            d1, DU, net->d2w, net->d2b, K, lg, Bc, 0, nullptr);
         head_output_kernel<<<(Bc + 63) / 64, 64, 0, st>>>(lg, y + (size_t)b0 * K, Bc, K, d.out_lo, d.out_hi);
         if (logits)
             AMT_HIP_CHECK(hipMemcpyAsync(logits + (size_t)b0 * K, lg, (size_t)Bc * K * sizeof(float),
