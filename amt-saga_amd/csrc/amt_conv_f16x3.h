@@ -176,13 +176,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
         for (int i = 0; i < WPT; ++i)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
     };
-    if (!(HX_ABLATE & 16)) {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
-        if (NGT > 1) issue(1);
-    }
+    if (!(HX_ABLATE & 16)) issue(0);                 // lands while the first tile is being staged
     if (MASKED && tid < 20) {                                        // the all-zero position (80 B), written once
         reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
     }
@@ -234,6 +228,12 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
                     }
                 }
             }
+        }
+        if (!(HX_ABLATE & 16) && ch == 0) {          // weight group 0 -> LDS, group 1 -> prefetch registers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
+            if (NGT > 1) issue(1);
         }
         // ---- K loop.  Weights travel global -> registers -> LDS in GROUPS of 4 steps (16 KB),
         //  double-buffered: one barrier per group (24 MFMAs per wave), the next group's loads are
