@@ -1,0 +1,147 @@
+"""CPU: the RDCNN oracle (oracle/rdcnn.py, numpy) against PyTorch's own fp32 operators.
+
+The reference ships neither weights nor recorded network outputs, so the oracle cannot be
+pinned against Keras itself.  What can be checked independently is that its building
+blocks compute what the framework documentation says they compute: this file re-evaluates the
+same graph with torch.nn.functional (a third-party implementation of conv / batch-norm /
+pooling / linear) and requires agreement to float32 rounding.  The asymmetric "same" padding
+of even kernels (TensorFlow: pad_before = (k-1)//2, the rest after) is applied explicitly on
+the torch side, as TF documents it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rdcnn as orc
+
+
+def _t(x):            # NHWC numpy -> NCHW torch
+    return torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2).contiguous()
+
+
+def _n(x):            # NCHW torch -> NHWC numpy
+    return x.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def _conv_same_torch(x, k, b):
+    kh, kw = k.shape[:2]
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    xp = F.pad(_t(x), (pl, kw - 1 - pl, pt, kh - 1 - pt))
+    w = torch.from_numpy(np.ascontiguousarray(k)).permute(3, 2, 0, 1).contiguous()
+    return _n(F.conv2d(xp, w, torch.from_numpy(b)))
+
+
+@pytest.mark.parametrize('kh,kw,cin,cout,H,W', [(4, 16, 1, 32, 20, 37), (4, 16, 32, 32, 7, 21),
+                                                  (4, 2, 32, 64, 11, 8), (2, 2, 64, 64, 5, 3),
+                                                  (3, 3, 8, 8, 6, 6)])
+def test_conv_same(kh, kw, cin, cout, H, W):
+    rng = np.random.default_rng(kh * 100 + kw)
+    x = rng.standard_normal((2, H, W, cin)).astype(np.float32)
+    k = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got, want = orc.conv2d_same(x, k, b), _conv_same_torch(x, k, b)
+    assert got.shape == want.shape == (2, H, W, cout)
+    assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1.0)
+    # an impulse shows the padding split directly: output (r, c) = k[pt + r0 - r, pl + c0 - c]
+    imp = np.zeros((1, H, W, 1), np.float32)
+    r0, c0 = H // 2, W // 2
+    imp[0, r0, c0, 0] = 1.0
+    k1 = rng.standard_normal((kh, kw, 1, 1)).astype(np.float32)
+    y = orc.conv2d_same(imp, k1, np.zeros(1, np.float32))[0, :, :, 0]
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    for dy in range(kh):
+        for dx in range(kw):
+            r, c = r0 + pt - dy, c0 + pl - dx
+            if 0 <= r < H and 0 <= c < W:
+                assert y[r, c] == k1[dy, dx, 0, 0]
+
+
+def test_batchnorm_pool_dense():
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((3, 10, 9, 16)).astype(np.float32)
+    w = {'p/gamma': rng.uniform(0.5, 2, 16).astype(np.float32), 'p/beta': rng.standard_normal(16).astype(np.float32),
+         'p/mean': rng.standard_normal(16).astype(np.float32), 'p/var': rng.uniform(0.2, 3, 16).astype(np.float32)}
+    want = _n(F.batch_norm(_t(x), torch.from_numpy(w['p/mean']), torch.from_numpy(w['p/var']),
+                           torch.from_numpy(w['p/gamma']), torch.from_numpy(w['p/beta']), False, 0.0, 1e-3))
+    assert np.abs(orc.batchnorm(x, w, 'p') - want).max() < 1e-5
+    for pool in ((2, 2), (2, 8), (3, 1)):
+        assert np.array_equal(orc.pool2d(x, pool, 'max'), _n(F.max_pool2d(_t(x), pool)))
+        assert np.abs(orc.pool2d(x, pool, 'avg') - _n(F.avg_pool2d(_t(x), pool))).max() < 1e-6
+
+
+def _forward_torch(w, cfg, xs):
+    """The graph of RDCNN.py:176-233 written with torch.nn.functional."""
+    tw = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}
+
+    def bn(x, p):
+        return F.batch_norm(x, tw[p + '/mean'], tw[p + '/var'], tw[p + '/gamma'], tw[p + '/beta'], False, 0.0, 1e-3)
+
+    flats = []
+    rfreq = cfg['residual_layer_frequencies']
+    for t, x in enumerate(xs):
+        p1 = _t(np.asarray(x, np.float32))
+        p0 = [p1] * len(rfreq)
+        for i in range(1, cfg['convolutional_layer_count'] + 1):
+            k = tw['t%d/conv%d/kernel' % (t, i)]
+            kh, kw = k.shape[:2]
+            pt, pl = (kh - 1) // 2, (kw - 1) // 2
+            p1 = F.conv2d(F.pad(p1, (pl, kw - 1 - pl, pt, kh - 1 - pt)), k.permute(3, 2, 0, 1).contiguous(),
+                          tw['t%d/conv%d/bias' % (t, i)])
+            p1 = torch.sigmoid(bn(p1, 't%d/bn%d' % (t, i)))
+            for ri in range(len(rfreq)):
+                if i % rfreq[ri] == 0:
+                    a = p0[ri]
+                    if a.shape != p1.shape:
+                        if a.shape[1] != p1.shape[1]:
+                            sk = tw['t%d/sc%d/kernel' % (t, i)]
+                            a = F.conv2d(a, sk.permute(3, 2, 0, 1).contiguous(), tw['t%d/sc%d/bias' % (t, i)])
+                        if a.shape[2:] != p1.shape[2:]:
+                            st = (a.shape[2] // p1.shape[2], a.shape[3] // p1.shape[3])
+                            a = F.avg_pool2d(a, st)
+                        a = bn(a, 't%d/scbn%d' % (t, i))
+                    p1 = bn(a + p1, 't%d/resbn%d' % (t, i))
+                    p0[ri] = p1
+            if cfg['pool_layer_frequency'] and i % cfg['pool_layer_frequency'] == 0:
+                p1 = F.max_pool2d(p1, tuple(cfg['pool_sizes'][t]))
+        flats.append(p1.permute(0, 2, 3, 1).reshape(p1.shape[0], -1))      # Keras flatten: (H, W, C)
+    c = torch.cat(flats, 1)
+    m = torch.sigmoid(c @ tw['dense1/kernel'] + tw['dense1/bias'])
+    return (m @ tw['dense2/kernel'] + tw['dense2/bias']).numpy()
+
+
+@pytest.mark.parametrize('name', ['velocity', 'pitch'])
+def test_full_forward_logits(name):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'amt-saga_amd'))
+    from amt_saga import heads, hyperparams
+    p = hyperparams.Hyperparams(N=2048)
+    h = heads.VelocityClassifier(p) if name == 'velocity' else heads.pitch_classifier(p)
+    cfg = orc.head_config(p, name)
+    rng = np.random.default_rng(3)
+    xs = [(rng.random((2,) + tuple(s[:2]) + (1,)) ** 2).astype(np.float32) for s in cfg['input_shapes']]
+    got = orc.forward(h.weights, cfg, xs, np.float32, return_logits=True)
+    want = _forward_torch(h.weights, cfg, xs)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-4 * max(np.abs(want).max(), 1.0)
+
+
+def test_oracle_stft_istft_vs_scipy():
+    """oracle.audio.stft/istft (librosa semantics restated) against scipy.signal: centred frames
+    with reflect ('even') extension, periodic Hann, no scaling; scipy divides by sum(window)."""
+    from scipy import signal
+    from oracle import audio as oa
+    rng = np.random.default_rng(11)
+    for n_fft, hop, L in ((512, 128, 128 * 40), (2048, 512, 512 * 21), (1024, 256, 256 * 33 + 77)):
+        x = rng.standard_normal(L).astype(np.float32)
+        D = oa.stft(x, n_fft, hop)
+        win = signal.get_window('hann', n_fft, fftbins=True)
+        _, _, Z = signal.stft(x.astype(np.float64), window=win, nperseg=n_fft, noverlap=n_fft - hop,
+                              boundary='even', padded=False, return_onesided=True)
+        Z = Z * win.sum()
+        T = min(D.shape[1], Z.shape[1])
+        assert abs(D.shape[1] - Z.shape[1]) <= 1          # scipy drops a trailing partial frame
+        assert np.abs(D[:, :T] - Z[:, :T]).max() < 2e-4 * np.abs(Z).max()
+        # inverse: both recover the signal (COLA)
+        y = oa.istft(D, hop)
+        n = min(len(y), L)
+        assert np.abs(y[:n] - x[:n]).max() < 1e-4
