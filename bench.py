@@ -254,6 +254,14 @@ def main():
                        'parallelism': 'windows sharded x%d, event all-gather' % world},
             'roofline': roofline, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
             'events_checksum': int(events.to(torch.int64).sum().item()),
+            'arithmetic_note': {
+                0: 'convolutions on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)',
+                1: 'f32-equivalent: every f32 operand split exactly into 3 bf16 terms, 6 MFMAs per product '
+                   'block, f32 accumulate; same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py)',
+                2: 'f32-equivalent: every f32 operand = f16 h + 2^-11 f16 l (22 significand bits, power-of-two '
+                   'range scaling), 3 MFMAs per product block, f32 accumulate, <= 3*2^-24 relative per product; '
+                   'same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py); --conv-mode 0 runs the f32 MFMA',
+            }[conv_mode],
         }
         if cpu:
             out['speedup_vs_cpu_baseline'] = round(value / cpu['value'], 1)
