@@ -41,10 +41,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Diagnostic builds only (scripts/ablate_conv.sh): -DHX_ABLATE=<bits> removes one phase to price it.
 //   1 staging loads + split   2 epilogue   4 MFMAs   8 A-fragment LDS reads   16 B-fragment global loads
 //   32 split + LDS write of the staged values (loads kept)   64 three loads in flight per thread while staging
+//   512 epilogue stores   1024 epilogue shortcut loads
 #ifndef HX_ABLATE
 #define HX_ABLATE 0
 #endif
 #define HX_PSTRIDE 80                        // bytes per staged position: 2 planes x 16 ch x 2 B + 16 pad
+#define HX_TPITCH 36                         // floats per row of the epilogue's transposition patch
 #define HX_LSCALE 2048.0f                    // 2^11
 #define HX_MINNORM 6.103515625e-05f          // 2^-14
 
@@ -317,44 +319,57 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
             if (role == 0) res[0][e] += o; else res[1][e] = o + res[1][e];     // tap-half 0 + tap-half 1
         }
     }
-    // ---- epilogue ------------------------------------------------------------------------------
-    const int j = cout_off + (NT == 1 ? 0 : role * 32) + (lane & 31);
+    // ---- epilogue: BN + sigmoid per lane (lane = output channel), then the wave's 32 x 32 tile is
+    // turned through a wave-private LDS patch ([row][36]) so that a lane owns 4 consecutive channels
+    // of a position: shortcut loads and output stores are 16 bytes per lane (4 x 1 KB per tile
+    // instead of 16 x 256 B), same arithmetic in the same order.
+    __syncthreads();                                      // input tile / exchange buffer no longer read
+    float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
+    const int jb = cout_off + (NT == 1 ? 0 : role * 32);
+    const int j = jb + (lane & 31);
+    const int c4 = (lane & 7) * 4;
     const float out_scale = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
     const float s1 = p.s1[j] * out_scale, t1 = p.t1[j];
-    const float s2 = p.s2 ? p.s2[j] : 1.f, t2 = p.t2 ? p.t2[j] : 0.f;
-    constexpr int EPB = 4;
+    float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + jb + c4);
+    if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + jb + c4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         if (NT == 1 && mt != role) continue;
         if (HX_ABLATE & 2) { if (res[mt][0] == 123.456f) p.out[tid] = res[mt][1]; continue; }
 #pragma unroll
-        for (int half = 0; half < 16 / EPB; ++half) {
-            int spq[EPB], gwq[EPB];
-            float scv[EPB];
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            tb[row * HX_TPITCH + (lane & 31)] = sigmoidf_(res[mt][e] * s1 + t1);
+        }
+        int spq[4], gwq[4];
+        float4 scv[4];
 #pragma unroll
-            for (int e8 = 0; e8 < EPB; ++e8) {
-                const int e = half * EPB + e8;
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int q = pg * 64 + mt * 32 + row;
-                spq[e8] = pos_sp[q];
-                gwq[e8] = pos_win[q];
+        for (int i = 0; i < 4; ++i) {
+            const int q = pg * 64 + mt * 32 + (lane >> 3) + 8 * i;
+            spq[i] = pos_sp[q];
+            gwq[i] = pos_win[q];
+        }
+        if (p.sc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *scp = p.sc + (size_t)gwq[i] * p.sc_win_stride + (size_t)max(spq[i], 0) * p.cout_total + jb + c4;
+                scv[i] = (spq[i] >= 0 && !(HX_ABLATE & 1024)) ? *reinterpret_cast<const float4 *>(scp)
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
+            if (spq[i] < 0) continue;
             if (p.sc) {
-#pragma unroll
-                for (int e8 = 0; e8 < EPB; ++e8) {
-                    const float *scp = p.sc + (size_t)gwq[e8] * p.sc_win_stride + (size_t)max(spq[e8], 0) * p.cout_total + j;
-                    scv[e8] = spq[e8] >= 0 ? scp[0] : 0.f;
-                }
+                v.x = (v.x + scv[i].x) * s2v.x + t2v.x;
+                v.y = (v.y + scv[i].y) * s2v.y + t2v.y;
+                v.z = (v.z + scv[i].z) * s2v.z + t2v.z;
+                v.w = (v.w + scv[i].w) * s2v.w + t2v.w;
             }
-#pragma unroll
-            for (int e8 = 0; e8 < EPB; ++e8) {
-                const int e = half * EPB + e8;
-                if (spq[e8] < 0) continue;
-                float *o = p.out + (size_t)gwq[e8] * p.out_win_stride + (size_t)spq[e8] * p.cout_total + j;
-                float v = sigmoidf_(res[mt][e] * s1 + t1);
-                if (p.sc) v = (v + scv[e8]) * s2 + t2;
-                o[0] = v;
-            }
+            float *o = p.out + (size_t)gwq[i] * p.out_win_stride + (size_t)spq[i] * p.cout_total + jb + c4;
+            if (!(HX_ABLATE & 512) || v.x == 123.456f) *reinterpret_cast<float4 *>(o) = v;
         }
     }
 }

@@ -1028,7 +1028,7 @@ static int launch_conv16(const ConvOp &c, const ConvParams &p, hipStream_t st) {
 
 // ---- split-fp16 variant: tile choice and launch ---------------------------------------------
 #define HX_SLAB_BYTES 4096
-#define HX_XCHG_BYTES (8 * 16 * 64 * 4)         // K-split partial-sum exchange (COUT = 32)
+#define HX_XCHG_BYTES (8 * 32 * HX_TPITCH * 4)  // epilogue transposition patches (>= the K-split exchange, 8 x 4 KB)
 static void choose_tile_h(ConvOp &c) {
     double best = -1;
     const int pcap = 256;
