@@ -606,9 +606,12 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, 
     const int RPW = TW + KW - 1, THin = TH + KH - 1;
     int *pos_rc = reinterpret_cast<int *>(smem);            // [PCAP] r | c << 16 (tile-local)
     int *pos_sp = pos_rc + C1M_PCAP;                         // [PCAP] global spatial index or -1
-    float *xt = reinterpret_cast<float *>(pos_sp + C1M_PCAP);   // [THin][RPW]
+    float *tpatch = reinterpret_cast<float *>(pos_sp + C1M_PCAP);   // [4 waves][32][HX_TPITCH]
+    float *xt = tpatch + 4 * 32 * HX_TPITCH;                 // [THin][RPW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *tb = tpatch + wid * 32 * HX_TPITCH;
+    const int c4 = (lane & 7) * 4;
     const int PT = TH * TW, nmt = (PT + 31) >> 5;
     for (int q = tid; q < C1M_PCAP; q += 256) {
         const int r = q / TW, c = q - r * TW;
@@ -619,7 +622,9 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, 
 #pragma unroll
     for (int i = 0; i < NK2; ++i) bq[i] = p.w[(2 * i + (lane >> 5)) * 32 + co];
     const float s1 = p.s1[co], t1 = p.t1[co];
-    const float s2 = p.s2 ? p.s2[co] : 1.f, t2 = p.t2 ? p.t2[co] : 0.f;
+    float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + c4);
+    if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + c4);
     const long total = (long)p.B * tiles_h * tiles_w;
     for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int tc = (int)(tile % tiles_w);
@@ -653,14 +658,24 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, 
                 const float a = xt[abase + dy * RPW + dx];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[i], acc, 0, 0, 0);
             }
+            // turn the 32 x 32 tile through a wave-private LDS patch: 16-byte stores, 4 channels per lane
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                tb[row * HX_TPITCH + co] = sigmoidf_(acc[e] * s1 + t1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lane >> 3) + 8 * i;
                 const int sp = pos_sp[mt * 32 + row];
+                float4 v = *reinterpret_cast<const float4 *>(tb + row * HX_TPITCH + c4);
                 if (sp < 0) continue;
-                float v = sigmoidf_(acc[e] * s1 + t1);
-                if (p.sc) v = (v + p.sc[(size_t)b * p.sc_win_stride + (size_t)sp * 32 + co]) * s2 + t2;
-                p.out[(size_t)b * p.out_win_stride + (size_t)sp * 32 + co] = v;
+                if (p.sc) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(p.sc + (size_t)b * p.sc_win_stride + (size_t)sp * 32 + c4);
+                    v.x = (v.x + sc.x) * s2v.x + t2v.x; v.y = (v.y + sc.y) * s2v.y + t2v.y;
+                    v.z = (v.z + sc.z) * s2v.z + t2v.z; v.w = (v.w + sc.w) * s2v.w + t2v.w;
+                }
+                *reinterpret_cast<float4 *>(p.out + (size_t)b * p.out_win_stride + (size_t)sp * 32 + c4) = v;
             }
         }
     }
@@ -1562,7 +1577,8 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     int TH1 = 1, TW1 = 1;
                     choose_tile1(H, W, &TH1, &TW1);
                     const int th = (H + TH1 - 1) / TH1, twn = (W + TW1 - 1) / TW1;
-                    const size_t lds = (size_t)2 * C1M_PCAP * 4 + (size_t)(TH1 + c.kh - 1) * (TW1 + c.kw - 1) * 4;
+                    const size_t lds = (size_t)2 * C1M_PCAP * 4 + (size_t)4 * 32 * HX_TPITCH * 4 +
+                                       (size_t)(TH1 + c.kh - 1) * (TW1 + c.kw - 1) * 4;
                     const unsigned grid = (unsigned)std::min<size_t>((size_t)Bc * th * twn, 256 * 8);
                     if (c.kh == 4 && c.kw == 16) conv1_mfma_kernel<4, 16><<<grid, 256, lds, st>>>(cp, TH1, TW1, th, twn);
                     else if (c.kh == 4 && c.kw == 2) conv1_mfma_kernel<4, 2><<<grid, 256, lds, st>>>(cp, TH1, TW1, th, twn);
