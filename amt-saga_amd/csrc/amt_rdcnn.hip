@@ -723,18 +723,29 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjParams p) {
         smem[i] = a * inv;
     }
     __syncthreads();
+    // four consecutive output channels per thread: 16-byte weight loads and output stores
     float *o = p.out + (size_t)b * p.out_win_stride + ((size_t)ho * p.WO + wo0) * p.COUT;
-    for (int i = threadIdx.x; i < nwo * p.COUT; i += 256) {
-        const int wl = i / p.COUT, co = i - wl * p.COUT;
-        float acc;
+    const int C4 = p.COUT >> 2;
+    for (int i = threadIdx.x; i < nwo * C4; i += 256) {
+        const int wl = i / C4, co = (i - wl * C4) << 2;
+        float4 acc;
         if (p.w) {
-            acc = 0.f;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *pv = smem + wl * p.CIN;
-            for (int ci = 0; ci < p.CIN; ++ci) acc = fmaf(pv[ci], p.w[ci * p.COUT + co], acc);
+            for (int ci = 0; ci < p.CIN; ++ci) {
+                const float4 wv = *reinterpret_cast<const float4 *>(p.w + (size_t)ci * p.COUT + co);
+                const float a = pv[ci];
+                acc.x = fmaf(a, wv.x, acc.x); acc.y = fmaf(a, wv.y, acc.y);
+                acc.z = fmaf(a, wv.z, acc.z); acc.w = fmaf(a, wv.w, acc.w);
+            }
         } else {
-            acc = smem[wl * p.CIN + co];
+            acc = *reinterpret_cast<const float4 *>(smem + wl * p.CIN + co);
         }
-        o[i] = acc * p.s[co] + p.t[co];
+        const float4 sv = *reinterpret_cast<const float4 *>(p.s + co);
+        const float4 tv = *reinterpret_cast<const float4 *>(p.t + co);
+        acc.x = acc.x * sv.x + tv.x; acc.y = acc.y * sv.y + tv.y;
+        acc.z = acc.z * sv.z + tv.z; acc.w = acc.w * sv.w + tv.w;
+        *reinterpret_cast<float4 *>(o + (size_t)wl * p.COUT + co) = acc;
     }
 }
 
@@ -743,19 +754,24 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
                                                        size_t in_win_stride, float *__restrict__ out,
                                                        size_t out_win_stride, int B, int H, int W,
                                                        int C, int PH, int PW, int HO, int WO) {
-    const size_t total = (size_t)B * HO * WO * C;
+    // four channels per thread (C is a multiple of 32): 16-byte loads and stores
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * HO * WO * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        size_t r = i / C;
+        const int c = (int)(i % C4) << 2;
+        size_t r = i / C4;
         const int wo = (int)(r % WO); r /= WO;
         const int ho = (int)(r % HO);
         const int b = (int)(r / HO);
         const float *x = in + (size_t)b * in_win_stride;
-        float m = -INFINITY;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int dy = 0; dy < PH; ++dy)
-            for (int dx = 0; dx < PW; ++dx)
-                m = fmaxf(m, x[((size_t)(ho * PH + dy) * W + (wo * PW + dx)) * C + c]);
-        out[(size_t)b * out_win_stride + ((size_t)ho * WO + wo) * C + c] = m;
+            for (int dx = 0; dx < PW; ++dx) {
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    x + ((size_t)(ho * PH + dy) * W + (wo * PW + dx)) * C + c);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        *reinterpret_cast<float4 *>(out + (size_t)b * out_win_stride + ((size_t)ho * WO + wo) * C + c) = m;
     }
 }
 
@@ -1614,7 +1630,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     const bool last = (i == L - 1);
                     float *po = last ? flatbuf + flat_off : pick(cur, p0, nullptr);
                     const size_t po_stride = last ? (size_t)flat : (size_t)HO * WO * c.cout;
-                    maxpool_kernel<<<grid_for((size_t)Bc * HO * WO * c.cout), 256, 0, st>>>(
+                    maxpool_kernel<<<grid_for((size_t)Bc * HO * WO * c.cout / 4), 256, 0, st>>>(
                         cur, cur_stride, po, po_stride, Bc, H, W, c.cout, tw.ph, tw.pw, HO, WO);
                     cur = po; cur_stride = po_stride; H = HO; W = WO;
                 }
