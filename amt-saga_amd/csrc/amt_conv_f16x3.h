@@ -38,6 +38,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic builds only (scripts/ablate_conv.sh): -DHX_ABLATE=<bits> removes one phase to price it.
 //   1 staging loads + split   2 epilogue   4 MFMAs   8 A-fragment LDS reads   16 B-fragment global loads
 //   32 split + LDS write of the staged values (loads kept)   64 three loads in flight per thread while staging
@@ -371,5 +372,262 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
             float *o = p.out + (size_t)gwq[i] * p.out_win_stride + (size_t)spq[i] * p.cout_total + jb + c4;
             if (!(HX_ABLATE & 512) || v.x == 123.456f) *reinterpret_cast<float4 *>(o) = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// COUT = 32 form: one 32-position M-tile per wave, every tap, software-pipelined fragments.
+//
+// In conv_f16x3_kernel a wave holds four accumulators (two M-tiles x hi/lo = 64 VGPRs), which
+// leaves hipcc one fragment register set: it reads an A fragment, waits, issues one or two
+// MFMAs, reads the next -- an LDS round trip in front of nearly every MFMA pair.  With a single
+// 32-channel N-tile the K-split that kept eight waves busy on 256 positions is not needed either:
+// here wave w simply owns positions 32w .. 32w+31 and walks all taps (accumulators: 32 VGPRs), and
+// the freed registers hold TWO taps of fragments (A h/l + B h/l = 16 VGPRs each): while the three
+// MFMAs of tap t run, the four ds_read_b128 of tap t+1 are already in flight
+// (sched_barriers keep hipcc from sinking them back).  No partial-sum exchange, same tile
+// geometry, staging, weight groups (8 taps = 16 KB) and epilogue.  A B fragment now feeds one
+// tile instead of two: 4 reads per 3 MFMAs, still well inside the LDS rate.
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int CIN>
+__global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const uint4 *__restrict__ w16s,
+                                                             HxScale hs) {
+    constexpr int NCHUNK = CIN / BX_CC;
+    constexpr int NTAPS = KH * KW;
+    constexpr int PCAP = 256;
+    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
+    static_assert(NTAPS % 2 == 0, "tap pairs");
+    constexpr int NSLAB = NTAPS / 2;                                // 4-KB slabs of two taps (host layout)
+    constexpr int SLAB_V4 = 256;
+    constexpr int GROUP = NSLAB >= 4 ? 4 : NSLAB;                   // slabs per weight group
+    constexpr int GT = 2 * GROUP;                                   // taps per group
+    constexpr int NG = NSLAB / GROUP, NGT = NCHUNK * NG;
+    constexpr int GV4 = GROUP * SLAB_V4;
+    constexpr int WPT = GV4 / 512;
+    static_assert(NSLAB % GROUP == 0 && GV4 % 512 == 0, "whole groups");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [2][GV4]
+    int *pos_sp = reinterpret_cast<int *>(wbuf + 2 * GV4);          // [PCAP]
+    int *pos_win = pos_sp + PCAP;
+    char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][80 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int THin = p.TH + KH - 1, TWin = p.TW + KW - 1;
+    const int RP = bx_row_pitch(p.TW, TWin);
+    const int cout_off = blockIdx.y * 32;
+    const uint4 *w16 = w16s + (size_t)blockIdx.y * ((size_t)NCHUNK * NSLAB * SLAB_V4);
+    int bid;
+    {
+        const int nx = gridDim.x, q8 = nx >> 3, r8 = nx & 7, xcd = blockIdx.x & 7;
+        bid = xcd * q8 + min(xcd, r8) + (blockIdx.x >> 3);
+    }
+    const int tc = bid % p.tiles_w; bid /= p.tiles_w;
+    const int tr = bid % p.tiles_h; bid /= p.tiles_h;
+    const int win0 = bid * p.NWIN;
+    const int r0 = tr * p.TH, c0 = tc * p.TW;
+    const int ptile = p.TH * p.TW;
+
+    int sa;
+    {
+        float bnd = hs.beta;
+        if (hs.alpha != 0.f) bnd += hs.alpha * hs.xmax[0];
+        int e = 0;
+        if (bnd > 0.f && bnd < 3.0e38f) (void)frexpf(bnd, &e);
+        sa = __builtin_amdgcn_readfirstlane(13 - e);
+    }
+    const float in_scale = __uint_as_float((unsigned)(127 + sa) << 23);
+
+    for (int q = tid; q < PCAP; q += 512) {
+        const int w_ = q / ptile, rem = q - w_ * ptile;
+        const int r = rem / p.TW, c = rem - r * p.TW;
+        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
+        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
+        pos_win[q] = win0 + w_;
+    }
+    // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
+    // PAIR of taps x 16 channels: k-groups 0,1 = tap t channels 0-7 / 8-15, k-groups 2,3 = tap t+1
+    // (the next column: +one position pitch).  Two 16-position M-subtiles x two 16-channel
+    // N-subtiles x (hi, lo) = eight 4-register accumulators.
+    int abase[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        int q = wid * 32 + ms * 16 + (lane & 15);
+        int w_ = q / ptile, rem = q - w_ * ptile;
+        int r = rem / p.TW, c = rem - r * p.TW;
+        if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
+        abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + ((lane >> 4) & 1) * 16 + (lane >> 5) * HX_PSTRIDE;
+    }
+    f32x4 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[ms][ns][e] = 0.f; lo[ms][ns][e] = 0.f; }
+
+    u32x4 wp[WPT];
+    auto issue = [&](int gg) {
+        const uint4 *src = w16 + (size_t)gg * GV4 + tid;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
+    };
+    issue(0);                                             // lands while the first tile is being staged
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        __syncthreads();
+        // ---- stage + split the input tile (16 channels), as in conv_f16x3_kernel ----------------
+        {
+            const int nrow = p.NWIN * THin;
+            const int items = nrow * TWin * 2;
+            constexpr int MAXIT = 2;
+            for (int it0 = 0; it0 < items; it0 += 512 * MAXIT) {
+                float4 v0[MAXIT], v1[MAXIT];
+                int dsto[MAXIT];
+#pragma unroll
+                for (int u = 0; u < MAXIT; ++u) {
+                    const int it = it0 + u * 512 + tid;
+                    v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u]; dsto[u] = -1;
+                    if (it < items) {
+                        const int cg = it & 1;
+                        const int pc = it >> 1;
+                        const int wr = pc / TWin, ci = pc - wr * TWin;
+                        const int w_ = wr / THin, ri = wr - w_ * THin;
+                        const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
+                        dsto[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
+                        if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
+                            const float4 *src = reinterpret_cast<const float4 *>(
+                                p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + ch * BX_CC + cg * 8);
+                            v0[u] = src[0]; v1[u] = src[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MAXIT; ++u) {
+                    if (dsto[u] < 0) continue;
+                    const float v[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                    unsigned short h[2][8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
+                    char *dst = in_lds + dsto[u];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        uint4 pk;
+                        pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+                        pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+                        pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+                        pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+                        *reinterpret_cast<uint4 *>(dst + pl * 32) = pk;
+                    }
+                }
+            }
+        }
+        if (ch == 0) {                                    // weight group 0 -> LDS, group 1 -> prefetch registers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
+            if (NGT > 1) issue(1);
+        }
+        __syncthreads();                                   // tile staged, weight group parked
+        union U { uint4 u; f16x8 v; };
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+            const int gg = ch * NG + g;
+            const uint4 *wb = wbuf + (gg & 1) * GV4 + lane;          // [tap pair][plane][N-subtile][64 lanes]
+            U aA[2], aB[2];                                          // A fragments of one M-subtile [plane]
+            U b[2][2][2];                                            // [buffer][N-subtile][plane]
+            auto loadA = [&](U (&a)[2], int tp, int ms) {
+                const int tap = g * GT + 2 * tp;
+                const int dy = tap / KW, dx = tap - dy * KW;
+                const char *ap = in_lds + abase[ms] + (dy * RP + dx) * HX_PSTRIDE;
+                a[0].u = *reinterpret_cast<const uint4 *>(ap);
+                a[1].u = *reinterpret_cast<const uint4 *>(ap + 32);
+            };
+            auto loadB = [&](U (&bb)[2][2], int tp) {
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) bb[ns][pl].u = wb[((tp * 2 + pl) * 2 + ns) * 64];
+            };
+            auto mfma6 = [&](int ms, U (&a)[2], U (&bb)[2][2]) {
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns) {
+                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, bb[ns][0].v, lo[ms][ns], 0, 0, 0);
+                    hi[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, bb[ns][0].v, hi[ms][ns], 0, 0, 0);
+                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, bb[ns][1].v, lo[ms][ns], 0, 0, 0);
+                }
+            };
+            loadA(aA, 0, 0);
+            loadB(b[0], 0);
+#pragma unroll
+            for (int tp = 0; tp < GT / 2; ++tp) {
+                const int cur = tp & 1;
+                loadA(aB, tp, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma6(0, aA, b[cur]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tp + 1 < GT / 2) { loadA(aA, tp + 1, 0); loadB(b[cur ^ 1], tp + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma6(1, aB, b[cur]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (gg + 1 < NGT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // group gg+1 has landed in registers
+                u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + ((gg + 1) & 1) * GV4);
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) dst[tid + i * 512] = wp[i];
+                if (gg + 2 < NGT) issue(gg + 2);
+            }
+            if (g + 1 < NG) __syncthreads();
+        }
+    }
+    // ---- epilogue (see conv_f16x3_kernel) -------------------------------------------------------
+    __syncthreads();
+    float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
+    const int c4 = (lane & 7) * 4;
+    const float out_scale = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
+    float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + cout_off + c4);
+    if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + cout_off + c4);
+    // D of a 16x16 MFMA: lane l holds rows 4*(l/16) + e, column l%16
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+        const int jn = cout_off + ns * 16 + (lane & 15);
+        const float s1 = p.s1[jn] * out_scale, t1 = p.t1[jn];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = ms * 16 + 4 * (lane >> 4) + e;
+                tb[row * HX_TPITCH + ns * 16 + (lane & 15)] =
+                    sigmoidf_((hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * s1 + t1);
+            }
+    }
+    int spq[4], gwq[4];
+    float4 scv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wid * 32 + (lane >> 3) + 8 * i;
+        spq[i] = pos_sp[q];
+        gwq[i] = pos_win[q];
+    }
+    if (p.sc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *scp = p.sc + (size_t)gwq[i] * p.sc_win_stride + (size_t)max(spq[i], 0) * p.cout_total + cout_off + c4;
+            scv[i] = spq[i] >= 0 ? *reinterpret_cast<const float4 *>(scp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
+        if (spq[i] < 0) continue;
+        if (p.sc) {
+            v.x = (v.x + scv[i].x) * s2v.x + t2v.x;
+            v.y = (v.y + scv[i].y) * s2v.y + t2v.y;
+            v.z = (v.z + scv[i].z) * s2v.z + t2v.z;
+            v.w = (v.w + scv[i].w) * s2v.w + t2v.w;
+        }
+        *reinterpret_cast<float4 *>(p.out + (size_t)gwq[i] * p.out_win_stride + (size_t)spq[i] * p.cout_total + cout_off + c4) = v;
     }
 }

@@ -896,6 +896,7 @@ struct ConvOp {
     double eff32 = 0, eff16 = 0;
     // split-fp16 variant (null when not built for this layer); N-slicing as for split-bf16
     uint4 *wh = nullptr;
+    uint4 *whs = nullptr;      // COUT = 32 layers: 16x16x32 fragments of tap pairs (conv_f16x3s_kernel)
     int THh = 0, TWh = 0, NWINh = 1;
     size_t ldsh = 0;
     bool maskedh = false;
@@ -1118,12 +1119,33 @@ static int launch_convh_t(const ConvOp &c, ConvParams p, const float *xmax, hipS
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
+template <int KH, int KW, int CIN>
+static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipStream_t st) {
+    auto kern = conv_f16x3s_kernel<KH, KW, CIN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        attr_set = true;
+    }
+    p.TH = c.THh; p.TW = c.TWh; p.NWIN = c.NWINh;
+    p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
+    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
+    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
+    HxScale hs{xmax, c.alpha, c.beta, c.sw};
+    kern<<<dim3(grid, c.nslice16), 512, c.ldsh, st>>>(p, c.whs, hs);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
 template <int KH, int KW>
 static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
 #define HX_CASE(CI, CO)                                                                    \
-    if (c.cin == CI && c.cw16 == CO)                                                       \
+    if (c.cin == CI && c.cw16 == CO) {                                                     \
+        if constexpr (CO == 32)                                                            \
+            if (!c.maskedh && c.whs && !(HX_ABLATE & 2048)) return launch_convs_t<KH, KW, CI>(c, p, xmax, st); \
         return c.maskedh ? launch_convh_t<KH, KW, CI, CO, true>(c, p, xmax, st)            \
-                         : launch_convh_t<KH, KW, CI, CO, false>(c, p, xmax, st);
+                         : launch_convh_t<KH, KW, CI, CO, false>(c, p, xmax, st);          \
+    }
     HX_CASE(32, 32) HX_CASE(32, 64) HX_CASE(64, 64) HX_CASE(128, 64)
 #undef HX_CASE
     return AMT_E_UNSUPPORTED;
@@ -1372,6 +1394,37 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                             amt_rdcnn_destroy(n); return AMT_E_HIP;
                         }
                         c.wh = static_cast<uint4 *>(dh);
+                        if (c.cw16 == 32 && !c.maskedh) {
+                            // [slice][chunk16][tap pair][plane][N-subtile][lane = col + 16 kgroup][8] f16:
+                            // kgroup 0,1 = first tap channels 0-7 / 8-15, kgroup 2,3 = second tap
+                            std::vector<unsigned short> ws((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
+                            const int ntp = ntap / 2;
+                            for (int sl = 0; sl < c.nslice16; ++sl)
+                                for (int ch = 0; ch < nch16; ++ch)
+                                    for (int tp = 0; tp < ntp; ++tp)
+                                        for (int ns = 0; ns < 2; ++ns)
+                                            for (int ln = 0; ln < 64; ++ln)
+                                                for (int jj = 0; jj < 8; ++jj) {
+                                                    const int col = ln & 15, kg = ln >> 4;
+                                                    const int tap = 2 * tp + (kg >> 1);
+                                                    const int cin_i = ch * BX_CC + 8 * (kg & 1) + jj;
+                                                    const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * 32 + ns * 16 + col];
+                                                    unsigned short hh[2];
+                                                    amt_split_f16<true>(wv * wscale, hh[0], hh[1]);
+                                                    for (int pl = 0; pl < 2; ++pl) {
+                                                        const size_t idx =
+                                                            ((((((size_t)sl * nch16 + ch) * ntp + tp) * 2 + pl) * 2 + ns) * 64 + ln) * 8 + jj;
+                                                        ws[idx] = hh[pl];
+                                                    }
+                                                }
+                            void *ds = nullptr;
+                            if (hipMalloc(&ds, ws.size() * 2) != hipSuccess) { amt_rdcnn_destroy(n); return AMT_E_NOMEM; }
+                            n->allocs.push_back(static_cast<float *>(ds));
+                            if (hipMemcpy(ds, ws.data(), ws.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                                amt_rdcnn_destroy(n); return AMT_E_HIP;
+                            }
+                            c.whs = static_cast<uint4 *>(ds);
+                        }
                     }
                 }
             }
