@@ -446,8 +446,9 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         pos_win[q] = win0 + w_;
     }
     // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
-    // PAIR of taps x 16 channels: k-groups 0,1 = tap t channels 0-7 / 8-15, k-groups 2,3 = tap t+1
-    // (the next column: +one position pitch).  Two 16-position M-subtiles x two 16-channel
+    // PAIR of taps x 16 channels: k-group g = (tap t + g%2, channels 8*(g/2) .. +7); the second tap
+    // is the next column (+one position pitch).  With this order the lanes a ds_read_b128 services
+    // together (0-3,12-15,20-27 ...) read 16 distinct slots or the same address: conflict-free.  Two 16-position M-subtiles x two 16-channel
     // N-subtiles x (hi, lo) = eight 4-register accumulators.
     int abase[2];
 #pragma unroll
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         int w_ = q / ptile, rem = q - w_ * ptile;
         int r = rem / p.TW, c = rem - r * p.TW;
         if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
-        abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + ((lane >> 4) & 1) * 16 + (lane >> 5) * HX_PSTRIDE;
+        abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16 + ((lane >> 4) & 1) * HX_PSTRIDE;
     }
     f32x4 hi[2][2], lo[2][2];
 #pragma unroll

@@ -1396,7 +1396,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         c.wh = static_cast<uint4 *>(dh);
                         if (c.cw16 == 32 && !c.maskedh) {
                             // [slice][chunk16][tap pair][plane][N-subtile][lane = col + 16 kgroup][8] f16:
-                            // kgroup 0,1 = first tap channels 0-7 / 8-15, kgroup 2,3 = second tap
+                            // kgroup g = (tap 2 tp + g % 2, channels 8 (g / 2) .. + 7)
                             std::vector<unsigned short> ws((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
                             const int ntp = ntap / 2;
                             for (int sl = 0; sl < c.nslice16; ++sl)
@@ -1406,8 +1406,8 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                                             for (int ln = 0; ln < 64; ++ln)
                                                 for (int jj = 0; jj < 8; ++jj) {
                                                     const int col = ln & 15, kg = ln >> 4;
-                                                    const int tap = 2 * tp + (kg >> 1);
-                                                    const int cin_i = ch * BX_CC + 8 * (kg & 1) + jj;
+                                                    const int tap = 2 * tp + (kg & 1);
+                                                    const int cin_i = ch * BX_CC + 8 * (kg >> 1) + jj;
                                                     const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * 32 + ns * 16 + col];
                                                     unsigned short hh[2];
                                                     amt_split_f16<true>(wv * wscale, hh[0], hh[1]);

@@ -189,10 +189,14 @@ def main():
     # split-bf16: every algorithmic f32 MAC costs six bf16 MFMA MACs, so the MFMA roof for the
     # ALGORITHMIC flops of this kernel is the dense bf16 peak / 6
     peak_tf = round(MFMA_BF16_PEAK_TF / nmf, 1) if split else MFMA_F32_PEAK_TF
-    kname = (('conv_f16x3_kernel<%d,%d,%d,%d> on %dx%d (3 x v_mfma_f32_32x32x16_f16 per f32 product block)'
-              if conv_mode == 2 else
-              'conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)')
-             if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
+    if split and conv_mode == 2 and dom_key[3] == 32:
+        kname = ('conv_f16x3s_kernel<%d,%d,%d> (Cout %d) on %dx%d (3 x v_mfma_f32_16x16x32_f16 per f32 product '
+                 'block of a tap pair)') % dom_key
+    else:
+        kname = (('conv_f16x3_kernel<%d,%d,%d,%d> on %dx%d (3 x v_mfma_f32_32x32x16_f16 per f32 product block)'
+                  if conv_mode == 2 else
+                  'conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)')
+                 if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tf):
