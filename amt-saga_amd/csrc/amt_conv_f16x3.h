@@ -474,54 +474,81 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         for (int i = 0; i < WPT; ++i)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
     };
-    issue(0);                                             // lands while the first tile is being staged
+    // staged items of this thread (the same for every chunk): two 32-byte items in the first pass
+    const int items = p.NWIN * THin * TWin * 2;
+    int sdst[2];                                           // LDS offset, -1: no item
+    const float *ssrc[2];                                  // chunk-0 source, null: outside the image (zeros)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = u * 512 + tid;
+        sdst[u] = -1; ssrc[u] = nullptr;
+        if (it < items) {
+            const int cg = it & 1, pc = it >> 1;
+            const int wr = pc / TWin, ci = pc - wr * TWin;
+            const int w_ = wr / THin, ri = wr - w_ * THin;
+            const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
+            sdst[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
+            if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W)
+                ssrc[u] = p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + cg * 8;
+        }
+    }
+    u32x4 sv[2][2];                                        // staged values in flight (inline-asm loads)
+    auto stage_issue = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float *src = ssrc[u] ? ssrc[u] + ch * BX_CC : p.in;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[u][0]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sv[u][1]) : "v"(src) : "memory");
+        }
+    };
+    auto split_store = [&](const float (&v)[8], int dsto) {
+        unsigned short h[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
+        char *dst = in_lds + dsto;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint4 pk;
+            pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+            pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+            pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+            pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+            *reinterpret_cast<uint4 *>(dst + pl * 32) = pk;
+        }
+    };
+    issue(0);                                             // first weight group: lands while the first tile is staged
+    stage_issue(0);
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
-        // ---- stage + split the input tile (16 channels), as in conv_f16x3_kernel ----------------
-        {
-            const int nrow = p.NWIN * THin;
-            const int items = nrow * TWin * 2;
-            constexpr int MAXIT = 2;
-            for (int it0 = 0; it0 < items; it0 += 512 * MAXIT) {
-                float4 v0[MAXIT], v1[MAXIT];
-                int dsto[MAXIT];
+        // ---- stage + split the input tile (16 channels).  The first pass (two items per thread) was
+        // issued ahead: for chunk 0 at kernel entry, for later chunks before the last weight group of
+        // the previous chunk, so its latency runs under that group's MFMAs. ------------------------
+        // chunk 0: wait here; later chunks: the values landed with the wait that closed the previous
+        // chunk's last weight group (waiting again would expose the weight loads issued since)
+        if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int u = 0; u < MAXIT; ++u) {
-                    const int it = it0 + u * 512 + tid;
-                    v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u]; dsto[u] = -1;
-                    if (it < items) {
-                        const int cg = it & 1;
-                        const int pc = it >> 1;
-                        const int wr = pc / TWin, ci = pc - wr * TWin;
-                        const int w_ = wr / THin, ri = wr - w_ * THin;
-                        const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
-                        dsto[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
-                        if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
-                            const float4 *src = reinterpret_cast<const float4 *>(
-                                p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + ch * BX_CC + cg * 8);
-                            v0[u] = src[0]; v1[u] = src[1];
-                        }
-                    }
-                }
+        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
 #pragma unroll
-                for (int u = 0; u < MAXIT; ++u) {
-                    if (dsto[u] < 0) continue;
-                    const float v[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
-                    unsigned short h[2][8];
+        for (int u = 0; u < 2; ++u) {
+            if (sdst[u] < 0) continue;
+            float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
-                    char *dst = in_lds + dsto[u];
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        uint4 pk;
-                        pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
-                        pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
-                        pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
-                        pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
-                        *reinterpret_cast<uint4 *>(dst + pl * 32) = pk;
-                    }
-                }
+            for (int e = 0; e < 8; ++e) v[e] = ssrc[u] ? __uint_as_float(sv[u][e >> 2][e & 3]) : 0.f;
+            split_store(v, sdst[u]);
+        }
+        for (int it = 1024 + tid; it < items; it += 512) {          // tiles with more than 1024 items
+            const int cg = it & 1, pc = it >> 1;
+            const int wr = pc / TWin, ci = pc - wr * TWin;
+            const int w_ = wr / THin, ri = wr - w_ * THin;
+            const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
+                const float4 *src = reinterpret_cast<const float4 *>(
+                    p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + ch * BX_CC + cg * 8);
+                const float4 x0 = src[0], x1 = src[1];
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
             }
+            split_store(v, (wr * RP + ci) * HX_PSTRIDE + cg * 16);
         }
         if (ch == 0) {                                    // weight group 0 -> LDS, group 1 -> prefetch registers
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -535,43 +562,37 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         for (int g = 0; g < NG; ++g) {
             const int gg = ch * NG + g;
             const uint4 *wb = wbuf + (gg & 1) * GV4 + lane;          // [tap pair][plane][N-subtile][64 lanes]
-            U aA[2], aB[2];                                          // A fragments of one M-subtile [plane]
-            U b[2][2][2];                                            // [buffer][N-subtile][plane]
-            auto loadA = [&](U (&a)[2], int tp, int ms) {
+            U a[2];                                                  // A fragments of one M-subtile [plane]
+            U b[2][2];                                               // [N-subtile][plane]
+            auto loadA = [&](int tp, int ms) {
                 const int tap = g * GT + 2 * tp;
                 const int dy = tap / KW, dx = tap - dy * KW;
                 const char *ap = in_lds + abase[ms] + (dy * RP + dx) * HX_PSTRIDE;
                 a[0].u = *reinterpret_cast<const uint4 *>(ap);
                 a[1].u = *reinterpret_cast<const uint4 *>(ap + 32);
             };
-            auto loadB = [&](U (&bb)[2][2], int tp) {
+            auto mfma6 = [&](int ms) {
+#pragma unroll
+                for (int ns = 0; ns < 2; ++ns) {
+                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, b[ns][0].v, lo[ms][ns], 0, 0, 0);
+                    hi[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[ns][0].v, hi[ms][ns], 0, 0, 0);
+                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[ns][1].v, lo[ms][ns], 0, 0, 0);
+                }
+            };
+            // next chunk's tile: loads fly under this (last) group's matrix work
+            if (g == NG - 1 && ch + 1 < NCHUNK) stage_issue(ch + 1);
+#pragma unroll
+            for (int tp = 0; tp < GT / 2; ++tp) {
 #pragma unroll
                 for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) bb[ns][pl].u = wb[((tp * 2 + pl) * 2 + ns) * 64];
-            };
-            auto mfma6 = [&](int ms, U (&a)[2], U (&bb)[2][2]) {
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) {
-                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, bb[ns][0].v, lo[ms][ns], 0, 0, 0);
-                    hi[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, bb[ns][0].v, hi[ms][ns], 0, 0, 0);
-                    lo[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, bb[ns][1].v, lo[ms][ns], 0, 0, 0);
-                }
-            };
-            loadA(aA, 0, 0);
-            loadB(b[0], 0);
-#pragma unroll
-            for (int tp = 0; tp < GT / 2; ++tp) {
-                const int cur = tp & 1;
-                loadA(aB, tp, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(0, aA, b[cur]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tp + 1 < GT / 2) { loadA(aA, tp + 1, 0); loadB(b[cur ^ 1], tp + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma6(1, aB, b[cur]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int pl = 0; pl < 2; ++pl) b[ns][pl].u = wb[((tp * 2 + pl) * 2 + ns) * 64];
+                loadA(tp, 0);
+                mfma6(0);
+                loadA(tp, 1);
+                mfma6(1);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (gg + 1 < NGT) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // group gg+1 has landed in registers
                 u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + ((gg + 1) & 1) * GV4);
