@@ -896,7 +896,8 @@ struct ConvOp {
     double eff32 = 0, eff16 = 0;
     // split-fp16 variant (null when not built for this layer); N-slicing as for split-bf16
     uint4 *wh = nullptr;
-    uint4 *whs = nullptr;      // COUT = 32 layers: 16x16x32 fragments of tap pairs (conv_f16x3s_kernel)
+    uint4 *whs = nullptr;      // 32-wide N-slices: 16x16x32 fragments of tap pairs (conv_f16x3s_kernel)
+    int nsliceh = 1, cwh = 0;  // split-fp16 N-slicing: 32-wide slices unless the layer runs the masked form
     int THh = 0, TWh = 0, NWINh = 1;
     size_t ldsh = 0;
     bool maskedh = false;
@@ -1066,7 +1067,7 @@ static void choose_tile_h(ConvOp &c) {
     const int pcap = 256;
     c.maskedh = false; c.THh = 0;
     // two weight-group buffers (a group = min(4, steps per chunk) steps of 4 KB)
-    const int NTh = c.cw16 / 32;
+    const int NTh = c.cwh / 32;
     const int nsteps = c.kh * c.kw / (NTh == 1 ? 2 : 1);
     const size_t wbytes = 2 * (size_t)std::min(4, nsteps) * HX_SLAB_BYTES;
     auto total = [&](size_t posbytes) {
@@ -1115,7 +1116,7 @@ static int launch_convh_t(const ConvOp &c, ConvParams p, const float *xmax, hipS
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
     HxScale hs{xmax, c.alpha, c.beta, c.sw};
-    kern<<<dim3(grid, c.nslice16), 512, c.ldsh, st>>>(p, c.wh, hs);
+    kern<<<dim3(grid, c.nsliceh), 512, c.ldsh, st>>>(p, c.wh, hs);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
@@ -1133,19 +1134,22 @@ static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipS
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
     HxScale hs{xmax, c.alpha, c.beta, c.sw};
-    kern<<<dim3(grid, c.nslice16), 512, c.ldsh, st>>>(p, c.whs, hs);
+    kern<<<dim3(grid, c.nsliceh), 512, c.ldsh, st>>>(p, c.whs, hs);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 template <int KH, int KW>
 static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
-#define HX_CASE(CI, CO)                                                                    \
-    if (c.cin == CI && c.cw16 == CO) {                                                     \
-        if constexpr (CO == 32)                                                            \
-            if (!c.maskedh && c.whs && !(HX_ABLATE & 2048)) return launch_convs_t<KH, KW, CI>(c, p, xmax, st); \
-        return c.maskedh ? launch_convh_t<KH, KW, CI, CO, true>(c, p, xmax, st)            \
-                         : launch_convh_t<KH, KW, CI, CO, false>(c, p, xmax, st);          \
+    // non-masked layers: 32-wide N-slices on the single-tile kernel; small images: the masked form
+    if (!c.maskedh) {
+        if (!c.whs || c.cwh != 32) return AMT_E_UNSUPPORTED;
+        if (c.cin == 32) return launch_convs_t<KH, KW, 32>(c, p, xmax, st);
+        if (c.cin == 64) return launch_convs_t<KH, KW, 64>(c, p, xmax, st);
+        if (c.cin == 128) return launch_convs_t<KH, KW, 128>(c, p, xmax, st);
+        return AMT_E_UNSUPPORTED;
     }
+#define HX_CASE(CI, CO)                                                                    \
+    if (c.cin == CI && c.cwh == CO) return launch_convh_t<KH, KW, CI, CO, true>(c, p, xmax, st);
     HX_CASE(32, 32) HX_CASE(32, 64) HX_CASE(64, 64) HX_CASE(128, 64)
 #undef HX_CASE
     return AMT_E_UNSUPPORTED;
@@ -1351,7 +1355,12 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         c.w16 = static_cast<uint4 *>(d16);
                     }
                     // split-fp16 weights: [slice][chunk16][slab][tt][plane(2)][nt][h][col][8] f16, scaled 2^sw
+                    c.nsliceh = c.nslice16; c.cwh = c.cw16;
                     choose_tile_h(c);
+                    if (!c.maskedh) {                                      // large images: 32-wide N-slices
+                        c.cwh = 32; c.nsliceh = fo / 32;
+                        choose_tile_h(c);
+                    }
                     float wmax = 0.f;
                     bool finite = std::isfinite(c.alpha) && std::isfinite(c.beta);
                     for (size_t q = 0; q < (size_t)ntap * C * fo; ++q) {
@@ -1363,12 +1372,12 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         (void)frexpf(wmax, &ew);                          // wmax < 2^ew
                         c.sw = 4 - ew;                                     // max |w| 2^sw in [8, 16)
                         const float wscale = ldexpf(1.0f, c.sw);
-                        const int NT16 = c.cw16 / 32;
+                        const int NT16 = c.cwh / 32;
                         const int tps = NT16 == 1 ? 2 : 1;
                         const int nslab = ntap / tps;
                         const int nch16 = C / BX_CC;
                         std::vector<unsigned short> whv((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
-                        for (int sl = 0; sl < c.nslice16; ++sl)
+                        for (int sl = 0; sl < c.nsliceh; ++sl)
                             for (int ch = 0; ch < nch16; ++ch)
                                 for (int sb = 0; sb < nslab; ++sb)
                                     for (int tt = 0; tt < tps; ++tt)
@@ -1378,7 +1387,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                                                     for (int jj = 0; jj < 8; ++jj) {
                                                         const int tap = sb * tps + tt;
                                                         const int cin_i = ch * BX_CC + 8 * h + jj;
-                                                        const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cw16 + nt * 32 + col];
+                                                        const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cwh + nt * 32 + col];
                                                         unsigned short hh[2];
                                                         amt_split_f16<true>(wv * wscale, hh[0], hh[1]);
                                                         for (int pl = 0; pl < 2; ++pl) {
@@ -1394,12 +1403,12 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                             amt_rdcnn_destroy(n); return AMT_E_HIP;
                         }
                         c.wh = static_cast<uint4 *>(dh);
-                        if (c.cw16 == 32 && !c.maskedh) {
+                        if (c.cwh == 32 && !c.maskedh) {
                             // [slice][chunk16][tap pair][plane][N-subtile][lane = col + 16 kgroup][8] f16:
                             // kgroup g = (tap 2 tp + g % 2, channels 8 (g / 2) .. + 7)
                             std::vector<unsigned short> ws((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
                             const int ntp = ntap / 2;
-                            for (int sl = 0; sl < c.nslice16; ++sl)
+                            for (int sl = 0; sl < c.nsliceh; ++sl)
                                 for (int ch = 0; ch < nch16; ++ch)
                                     for (int tp = 0; tp < ntp; ++tp)
                                         for (int ns = 0; ns < 2; ++ns)
