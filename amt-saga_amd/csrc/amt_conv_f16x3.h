@@ -47,6 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HX_ABLATE 0
 #endif
 #define HX_PSTRIDE 80                        // bytes per staged position: 2 planes x 16 ch x 2 B + 16 pad
+#define HXS_NIT 2                            // prefetched staging items per thread (conv_f16x3s_kernel); 3 measured slower (register pressure)
 #define HX_TPITCH 36                         // floats per row of the epilogue's transposition patch
 #define HX_LSCALE 2048.0f                    // 2^11
 #define HX_MINNORM 6.103515625e-05f          // 2^-14
@@ -474,12 +475,14 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         for (int i = 0; i < WPT; ++i)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
     };
-    // staged items of this thread (the same for every chunk): two 32-byte items in the first pass
+    // staged 32-byte items of this thread (the same for every chunk): up to HXS_NIT of them are
+    // prefetched; the third slot exists only in the waves that have one (tiles of 1025..1536 items)
     const int items = p.NWIN * THin * TWin * 2;
-    int sdst[2];                                           // LDS offset, -1: no item
-    const float *ssrc[2];                                  // chunk-0 source, null: outside the image (zeros)
+    int sdst[HXS_NIT];                                     // LDS offset, -1: no item
+    const float *ssrc[HXS_NIT];                            // chunk-0 source, null: outside the image (zeros)
+    const bool third = 2 * 512 + wid * 64 < items;         // wave-uniform
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < HXS_NIT; ++u) {
         const int it = u * 512 + tid;
         sdst[u] = -1; ssrc[u] = nullptr;
         if (it < items) {
@@ -492,10 +495,11 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 ssrc[u] = p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + cg * 8;
         }
     }
-    u32x4 sv[2][2];                                        // staged values in flight (inline-asm loads)
+    u32x4 sv[HXS_NIT][2];                                  // staged values in flight (inline-asm loads)
     auto stage_issue = [&](int ch) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < HXS_NIT; ++u) {
+            if (u == 2 && !third) continue;
             const float *src = ssrc[u] ? ssrc[u] + ch * BX_CC : p.in;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[u][0]) : "v"(src) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sv[u][1]) : "v"(src) : "memory");
@@ -527,16 +531,16 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         // chunk's last weight group (waiting again would expose the weight loads issued since)
         if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
+        for (int u = 0; u < HXS_NIT; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (sdst[u] < 0) continue;
+        for (int u = 0; u < HXS_NIT; ++u) {
+            if (sdst[u] < 0 || (u == 2 && !third)) continue;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = ssrc[u] ? __uint_as_float(sv[u][e >> 2][e & 3]) : 0.f;
             split_store(v, sdst[u]);
         }
-        for (int it = 1024 + tid; it < items; it += 512) {          // tiles with more than 1024 items
+        for (int it = HXS_NIT * 512 + tid; it < items; it += 512) { // tiles with more than 1536 items
             const int cg = it & 1, pc = it >> 1;
             const int wr = pc / TWin, ci = pc - wr * TWin;
             const int w_ = wr / THin, ri = wr - w_ * THin;
