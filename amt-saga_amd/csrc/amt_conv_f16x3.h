@@ -1,5 +1,5 @@
 // Split-fp16 convolution ("f16x3"): fp32-equivalent products on the f16 MFMA pipe with
-// THREE v_mfma_f32_32x32x16_f16 per 16-deep k-block (the split-bf16 kernel needs six).
+// THREE f16 MFMAs per 16-deep k-block of an f32 product (the split-bf16 kernel needs six).
 //
 // Every f32 operand x (scaled by a power of two into the f16 range) is written as
 //        x * 2^s = h + l * 2^-11,   h = f16(x 2^s),  l = f16((x 2^s - h) * 2^11)
@@ -23,17 +23,17 @@
 //   2^-14 (f16 subnormals) are flushed to zero in both terms: an absolute error below
 //   2^-25 of the scaled bound, i.e. < 2^-38 relative to the activation bound.
 //
-// Work decomposition (512 threads, two workgroups per CU, <= 128 VGPRs, spill-free):
-//   wave w: position group pg = w & 3 -> TWO 32-position M-tiles (q = pg*64 + mt*32 + lane%32),
-//           role r = w >> 2 -> COUT = 32: the odd/even tap of each 2-tap weight slab (K-split,
-//                               partial sums exchanged through LDS once, at the end)
-//                              COUT = 64: the N-tile (32 output channels)
-//   so a B fragment read from LDS feeds two MFMA tiles: 6 ds_read_b128 per 6 MFMAs that do
-//   the work of 12 bf16x6 MFMAs + 6 reads... i.e. half the LDS traffic and half the matrix
-//   cycles of the split-bf16 kernel per output.
-//   Staging (split while writing LDS, [pos][plane(2)][16 ch] f16 = 80-B pitch, 5 x 16-B slots:
-//   conflict-free b128), weight slabs (3 LDS buffers, inline-asm prefetch two slabs ahead),
-//   tile geometry, masked small-image form and epilogue follow conv_bf16x6_kernel.
+// Two kernels share the arithmetic (512 threads, two workgroups per CU, <= 128 VGPRs, spill-free;
+// input tile [pos][plane(2)][16 ch] f16 with an 80-B pitch = 5 x 16-B slots, split while staging;
+// weights global -> registers -> double-buffered LDS in 16-KB groups, one barrier per group):
+//   conv_f16x3s_kernel (below, second)  every layer on a large image: a wave owns ONE 32-position
+//       M-tile and 32 output channels (wider layers are split over blockIdx.y), walks all taps,
+//       v_mfma_f32_16x16x32_f16 on tap pairs, next chunk's input requested under the last weight group;
+//   conv_f16x3_kernel (first)  the masked small-image form (whole H x W <= 64 images of several
+//       windows per workgroup, no halo): wave w = position group w & 3 with TWO 32-position
+//       M-tiles, role w >> 2 = the odd/even tap of a tap pair (COUT 32, partial sums exchanged
+//       through LDS once) or the N-tile (COUT 64); v_mfma_f32_32x32x16_f16.
+// Tile geometry, masked form and N-slicing follow conv_bf16x6_kernel (amt_rdcnn.hip).
 #pragma once
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

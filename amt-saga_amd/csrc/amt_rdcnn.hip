@@ -1,5 +1,7 @@
-// RDCNN forward (res_net.predict) for gfx950: fp32-exact MFMA implicit-GEMM
-// convolutions with fused BN + sigmoid (+ shortcut add + BN) epilogues.
+// RDCNN forward (res_net.predict) for gfx950: implicit-GEMM convolutions on the matrix pipe
+// with fused BN + sigmoid (+ shortcut add + BN) epilogues, in three f32-equivalent arithmetics:
+//   mode 2 (default) split-fp16, amt_conv_f16x3.h;  mode 1 split-bf16, conv_bf16x6_kernel below;
+//   mode 0 f32 MFMA, conv_mfma_kernel below (described next).
 //
 // Replaces keras Model.predict for the graph built in
 // /root/reference/RDCNN.py:176-233 (+ _add_shortcut :312-335, output scaling
