@@ -637,18 +637,30 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         spq[i] = pos_sp[q];
         gwq[i] = pos_win[q];
     }
+    const bool has_sc = p.sc || p.sc1;
     if (p.sc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float *scp = p.sc + (size_t)gwq[i] * p.sc_win_stride + (size_t)max(spq[i], 0) * p.cout_total + cout_off + c4;
             scv[i] = spq[i] >= 0 ? *reinterpret_cast<const float4 *>(scp) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    } else if (p.sc1) {
+        // rank-1 shortcut: BN(conv1x1(x)) of the one-channel input, formed here as proj_kernel forms it
+        const float4 w4 = *reinterpret_cast<const float4 *>(p.sc1_w + cout_off + c4);
+        const float4 s4 = *reinterpret_cast<const float4 *>(p.sc1_s + cout_off + c4);
+        const float4 t4 = *reinterpret_cast<const float4 *>(p.sc1_t + cout_off + c4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = spq[i] >= 0 ? p.sc1[(size_t)gwq[i] * p.sc1_win_stride + spq[i]] : 0.f;
+            scv[i] = make_float4(fmaf(x, w4.x, 0.f) * s4.x + t4.x, fmaf(x, w4.y, 0.f) * s4.y + t4.y,
+                                 fmaf(x, w4.z, 0.f) * s4.z + t4.z, fmaf(x, w4.w, 0.f) * s4.w + t4.w);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
         if (spq[i] < 0) continue;
-        if (p.sc) {
+        if (has_sc) {
             v.x = (v.x + scv[i].x) * s2v.x + t2v.x;
             v.y = (v.y + scv[i].y) * s2v.y + t2v.y;
             v.z = (v.z + scv[i].z) * s2v.z + t2v.z;

@@ -48,6 +48,11 @@ struct ConvParams {
     int tiles_h, tiles_w;
     int cout_total;                              // channels of the output tensor (>= the kernel's COUT
                                                  // when the layer is split over blockIdx.y N-slices)
+    // rank-1 shortcut (conv_f16x3s_kernel): the first residual block projects the ONE-channel network
+    // input with a 1x1 kernel + BN (RDCNN.py:328-334); instead of materialising that [H][W][COUT]
+    // tensor the epilogue forms (x * w_c) * s_c + t_c itself -- the operations of proj_kernel
+    const float *sc1 = nullptr; size_t sc1_win_stride = 0;      // [B][H][W] (null: not used)
+    const float *sc1_w = nullptr, *sc1_s = nullptr, *sc1_t = nullptr;   // [COUT]
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -1629,8 +1634,12 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                 float *o = last_op ? flatbuf + flat_off : pick(cur, p0, nullptr);
                 const size_t o_stride = last_op ? (size_t)flat : (size_t)H * W * c.cout;
                 const float *sc = nullptr; size_t sc_stride = 0;
+                const ProjOp *rank1 = nullptr;
                 if (c.residual) {
-                    if (c.sc_proj >= 0) {
+                    if (c.sc_proj >= 0 && net->mode == 2 && c.wh && !c.maskedh && tw.projs[c.sc_proj].cin == 1 &&
+                        tw.projs[c.sc_proj].ph == 1 && tw.projs[c.sc_proj].pw == 1 && tw.projs[c.sc_proj].w) {
+                        rank1 = &tw.projs[c.sc_proj];                 // formed in the consumer's epilogue
+                    } else if (c.sc_proj >= 0) {
                         const ProjOp &pr = tw.projs[c.sc_proj];
                         float *sb = pick(cur, p0, o);
                         ProjParams pp{p0, p0_stride, sb, (size_t)pr.HO * pr.WO * pr.cout, pr.w, pr.s, pr.t,
@@ -1679,6 +1688,10 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
                                   Bc, H, W, c.TH, c.TW, c.NWIN, (H + c.TH - 1) / c.TH,
                                   (W + c.TW - 1) / c.TW, c.cout};
+                    if (rank1) {
+                        cp.sc1 = p0; cp.sc1_win_stride = p0_stride;
+                        cp.sc1_w = rank1->w; cp.sc1_s = rank1->s; cp.sc1_t = rank1->t;
+                    }
                     const int rc = (net->mode == 2 && c.wh) ? launch_convh(c, cp, xmax + t, st)
                                    : (net->mode >= 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
