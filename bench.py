@@ -263,7 +263,7 @@ def main():
                 1: 'f32-equivalent: every f32 operand split exactly into 3 bf16 terms, 6 MFMAs per product '
                    'block, f32 accumulate; same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py)',
                 2: 'f32-equivalent: every f32 operand = f16 h + 2^-11 f16 l (22 significand bits, power-of-two '
-                   'range scaling), 3 MFMAs per product block, f32 accumulate, <= 3*2^-24 relative per product; '
+                   'range scaling), 3 MFMAs per product block, f32 accumulate, ~1e-7 rms / <= 2^-21 worst case per product; '
                    'same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py); --conv-mode 0 runs the f32 MFMA',
             }[conv_mode],
         }
