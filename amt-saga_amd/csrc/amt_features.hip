@@ -29,11 +29,28 @@ __global__ __launch_bounds__(256) void compress_bands_kernel(
     }
     const float r = ref ? ref[b] : 1.0f;
     float *o = out + ((size_t)b * bands) * target + j;
+    // Bands that lie inside the first 64 bins (13 of the 20 log-spaced bands at F = 1025) are
+    // summed lane-per-band: lane i walks its band through wave shuffles of the first register --
+    // one pass of max-width steps for all of them instead of a 64-lane reduction each.  Wider
+    // bands: masked sums over the registers the band touches (uniform skips) + one wave reduction.
+    const int my_lo = lane < bands ? edges[lane] : 0, my_hi = lane < bands ? edges[lane + 1] : 0;
+    const bool narrow = lane < bands && my_hi <= 64;
+    int wmax = narrow ? my_hi - my_lo : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+    float sn = 0.f;
+    for (int k = 0; k < wmax; ++k) {
+        const float x = __shfl(v[0], (my_lo + k) & 63, 64);
+        if (narrow && my_lo + k < my_hi) sn += x;
+    }
+    if (narrow) o[(size_t)lane * target] = __fdiv_rn(__fdiv_rn(sn, (float)(my_hi - my_lo)), r);
     for (int i = 0; i < bands; ++i) {
         const int lo = edges[i], hi = edges[i + 1];
+        if (hi <= 64) continue;                                  // done above (uniform)
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
+            if (hi <= 64 * q || lo >= 64 * (q + 1)) continue;    // uniform: the band does not touch this register
             const int f = lane + 64 * q;
             s += (f >= lo && f < hi) ? v[q] : 0.f;
         }
