@@ -25,29 +25,19 @@
 //   2^-14 (f16 subnormals) are flushed to zero in both terms: an absolute error below
 //   2^-25 of the scaled bound, i.e. < 2^-38 relative to the activation bound.
 //
-// Two kernels share the arithmetic (512 threads, two workgroups per CU, <= 128 VGPRs, spill-free;
-// input tile [pos][plane(2)][16 ch] f16 with an 80-B pitch = 5 x 16-B slots, split while staging;
-// weights global -> registers -> double-buffered LDS in 16-KB groups, one barrier per group):
-//   conv_f16x3s_kernel (below, second)  every layer on a large image: a wave owns ONE 32-position
-//       M-tile and 32 output channels (wider layers are split over blockIdx.y), walks all taps,
-//       v_mfma_f32_16x16x32_f16 on tap pairs, next chunk's input requested under the last weight group;
-//   conv_f16x3_kernel (first)  the masked small-image form (whole H x W <= 64 images of several
-//       windows per workgroup, no halo): wave w = position group w & 3 with TWO 32-position
-//       M-tiles, role w >> 2 = the odd/even tap of a tap pair (COUT 32, partial sums exchanged
-//       through LDS once) or the N-tile (COUT 64); v_mfma_f32_32x32x16_f16.
-// Tile geometry, masked form and N-slicing follow conv_bf16x6_kernel (amt_rdcnn.hip).
+// conv_f16x3s_kernel (512 threads, two workgroups per CU, <= 128 VGPRs, spill-free): input tile
+// [pos][plane(2)][16 ch] f16 with an 80-B pitch = 5 x 16-B slots, split while staging; weights
+// global -> registers -> double-buffered LDS in 16-KB groups, one barrier per group; a wave owns ONE
+// 32-position M-tile and 32 output channels (wider layers are split over blockIdx.y) and walks all
+// taps with v_mfma_f32_16x16x32_f16 on tap pairs; the next chunk's input is requested under the last
+// weight group; small images (H x W <= 64) use the masked form (no halo).  Tile geometry and the
+// masked idea follow conv_bf16x6_kernel (amt_rdcnn.hip).  An earlier two-M-tiles-per-wave kernel on
+// v_mfma_f32_32x32x16_f16 and the experiments around it are recorded in profiles/r01/ablation_f16x3.txt.
 #pragma once
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// Diagnostic builds only (scripts/ablate_conv.sh): -DHX_ABLATE=<bits> removes one phase to price it.
-//   1 staging loads + split   2 epilogue   4 MFMAs   8 A-fragment LDS reads   16 B-fragment global loads
-//   32 split + LDS write of the staged values (loads kept)   64 three loads in flight per thread while staging
-//   512 epilogue stores   1024 epilogue shortcut loads
-#ifndef HX_ABLATE
-#define HX_ABLATE 0
-#endif
 #define HX_PSTRIDE 80                        // bytes per staged position: 2 planes x 16 ch x 2 B + 16 pad
 #define HXS_NIT 2                            // prefetched staging items per thread (conv_f16x3s_kernel); 3 measured slower (register pressure)
 #define HX_TPITCH 36                         // floats per row of the epilogue's transposition patch
@@ -92,294 +82,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
 }
 
-template <int KH, int KW, int CIN, int COUT, bool MASKED>
-__global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const uint4 *__restrict__ w16s,
-                                                            HxScale hs) {
-    constexpr int NT = COUT / 32;
-    static_assert(NT == 1 || NT == 2, "one or two N-tiles per workgroup");
-    constexpr int NCHUNK = CIN / BX_CC;
-    constexpr int NTAPS = KH * KW;
-    constexpr int PCAP = 256;
-    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
-    constexpr int TPS = (NT == 1) ? 2 : 1;                          // taps per weight slab
-    static_assert(NTAPS % TPS == 0, "even tap count");
-    constexpr int NSLAB = NTAPS / TPS;
-    constexpr int SLAB_V4 = TPS * 2 * NT * 64;                      // = 256 uint4 (4 KB)
-    static_assert(SLAB_V4 == 256, "one uint4 per thread of the lower half");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int GROUP = NSLAB >= 4 ? 4 : NSLAB;                   // steps per weight group
-    static_assert(NSLAB % GROUP == 0, "whole groups");
-    constexpr int NG = NSLAB / GROUP, NGT = NCHUNK * NG;            // groups per chunk / in all
-    constexpr int GV4 = GROUP * SLAB_V4;                            // uint4 per group (16 KB for 4 steps)
-    constexpr int WPT = GV4 / 512;                                  // uint4 per thread and group
-    static_assert(GV4 % 512 == 0, "whole uint4 per thread");
-    uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [2][GV4]
-    int *pos_sp = reinterpret_cast<int *>(wbuf + 2 * GV4);          // [PCAP]
-    int *pos_win = pos_sp + PCAP;
-    char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][80 B]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keep it in an SGPR
-    const int pg = wid & 3, role = wid >> 2;
-    const int THin = MASKED ? p.TH : p.TH + KH - 1, TWin = MASKED ? p.TW : p.TW + KW - 1;
-    const int RP = MASKED ? p.TW : bx_row_pitch(p.TW, TWin);
-    const int cout_off = blockIdx.y * COUT;
-    const uint4 *w16 = w16s + (size_t)blockIdx.y * ((size_t)NCHUNK * NSLAB * SLAB_V4);
-    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD one contiguous run of
-    // tiles -- neighbours that share halo columns / rows then share that XCD's L2
-    int bid;
-    {
-        const int nx = gridDim.x, q8 = nx >> 3, r8 = nx & 7, xcd = blockIdx.x & 7;
-        bid = xcd * q8 + min(xcd, r8) + (blockIdx.x >> 3);
-    }
-    const int tc = bid % p.tiles_w; bid /= p.tiles_w;
-    const int tr = bid % p.tiles_h; bid /= p.tiles_h;
-    const int win0 = bid * p.NWIN;
-    const int r0 = tr * p.TH, c0 = tc * p.TW;
-    const int ptile = p.TH * p.TW;
-
-    // activation scale 2^sa from the layer's input bound (identical in every lane)
-    int sa;
-    {
-        float bnd = hs.beta;
-        if (hs.alpha != 0.f) bnd += hs.alpha * hs.xmax[0];
-        int e = 0;
-        if (bnd > 0.f && bnd < 3.0e38f) (void)frexpf(bnd, &e);      // bnd < 2^e
-        sa = __builtin_amdgcn_readfirstlane(13 - e);
-    }
-    const float in_scale = __uint_as_float((unsigned)(127 + sa) << 23);          // 2^sa, |sa| < 120
-
-    for (int q = tid; q < PCAP; q += 512) {
-        const int w_ = q / ptile, rem = q - w_ * ptile;
-        const int r = rem / p.TW, c = rem - r * p.TW;
-        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
-        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
-        pos_win[q] = win0 + w_;
-    }
-    int abase[2];
-    unsigned lrc = 0;                                             // (row, col) of both M-tiles, 8 bits each
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int q = pg * 64 + mt * 32 + (lane & 31);
-        int w_ = q / ptile, rem = q - w_ * ptile;
-        int r = rem / p.TW, c = rem - r * p.TW;
-        if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
-        abase[mt] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16;
-        lrc |= ((unsigned)r | ((unsigned)c << 8)) << (16 * mt);
-    }
-    const int zero_off = p.NWIN * THin * RP * HX_PSTRIDE + (lane >> 5) * 16;
-    f32x16 hi[2], lo[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { hi[mt][e] = 0.f; lo[mt][e] = 0.f; }
-
-    // weight groups: group 0 straight into LDS, group 1 into the prefetch registers
-    u32x4 wp[WPT];
-    auto issue = [&](int gg) {
-        const uint4 *src = w16 + (size_t)gg * GV4 + tid;
-#pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
-    };
-    if (!(HX_ABLATE & 16)) issue(0);                 // lands while the first tile is being staged
-    if (MASKED && tid < 20) {                                        // the all-zero position (80 B), written once
-        reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
-    }
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-        __syncthreads();
-        // ---- stage + split the input tile (16 channels) ---------------------------------
-        if (!(HX_ABLATE & 1)) {
-            const int nrow = p.NWIN * THin;
-            const int items = nrow * TWin * 2;
-            constexpr int MAXIT = MASKED ? 1 : ((HX_ABLATE & 64) ? 3 : 2);   // masked tiles are one pass of <= 512 items
-            for (int it0 = 0; it0 < items; it0 += 512 * MAXIT) {
-                float4 v0[MAXIT], v1[MAXIT];
-                int dsto[MAXIT];
-#pragma unroll
-                for (int u = 0; u < MAXIT; ++u) {
-                    const int it = it0 + u * 512 + tid;
-                    v0[u] = make_float4(0.f, 0.f, 0.f, 0.f); v1[u] = v0[u]; dsto[u] = -1;
-                    if (it < items) {
-                        const int cg = it & 1;
-                        const int pc = it >> 1;
-                        const int wr = pc / TWin, ci = pc - wr * TWin;
-                        const int w_ = wr / THin, ri = wr - w_ * THin;
-                        const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
-                        dsto[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
-                        if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
-                            const float4 *src = reinterpret_cast<const float4 *>(
-                                p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + ch * BX_CC + cg * 8);
-                            v0[u] = src[0]; v1[u] = src[1];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < MAXIT; ++u) {
-                    if (dsto[u] < 0) continue;
-                    if (HX_ABLATE & 32) { asm volatile("" :: "v"(v0[u].x), "v"(v0[u].w), "v"(v1[u].x), "v"(v1[u].w)); continue; }
-                    const float v[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
-                    unsigned short h[2][8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
-                    char *dst = in_lds + dsto[u];
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        uint4 pk;
-                        pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
-                        pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
-                        pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
-                        pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
-                        *reinterpret_cast<uint4 *>(dst + pl * 32) = pk;
-                    }
-                }
-            }
-        }
-        if (!(HX_ABLATE & 16) && ch == 0) {          // weight group 0 -> LDS, group 1 -> prefetch registers
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
-            if (NGT > 1) issue(1);
-        }
-        // ---- K loop.  Weights travel global -> registers -> LDS in GROUPS of 4 steps (16 KB),
-        //  double-buffered: one barrier per group (24 MFMAs per wave), the next group's loads are
-        //  issued a whole group ahead.  (Per-step slabs cost a barrier per 6 MFMAs; per-wave B
-        //  loads straight from global cost 30 % in L1 throughput: profiles/r01/ablation_f16x3.txt.)
-        //  The loads are inline asm so that the compiler neither sinks them to their use nor
-        //  counts them; their destination registers must never be spilled while in flight
-        //  (checked by the build).
-        union U { uint4 u; f16x8 v; u32x4 r; };
-        const int fragoff = ((NT == 1) ? role * 2 : role) * 64 + lane;      // [tt][plane][nt][lane]
-        auto step = [&](int s_, const uint4 *wb) {
-            U b[2];
-            b[0].u = wb[0];
-            b[1].u = wb[NT * 64];
-            const int tap = s_ * TPS + ((NT == 1) ? role : 0);
-            const int dy = tap / KW, dx = tap - dy * KW;
-            auto a_ptr = [&](int mt) -> const char * {
-                if constexpr (MASKED) {
-                    const int rr = (int)((lrc >> (16 * mt)) & 255u) + dy - PAD_T;
-                    const int cc = (int)((lrc >> (16 * mt + 8)) & 255u) + dx - PAD_L;
-                    const bool inb = (unsigned)rr < (unsigned)p.H && (unsigned)cc < (unsigned)p.W;
-                    return in_lds + (inb ? abase[mt] + ((dy - PAD_T) * RP + (dx - PAD_L)) * HX_PSTRIDE : zero_off);
-                } else {
-                    return in_lds + abase[mt] + (dy * RP + dx) * HX_PSTRIDE;
-                }
-            };
-            auto a_read = [&](U (&a)[2], const char *ab) {
-                if (!(HX_ABLATE & 8)) {
-                    a[0].u = *reinterpret_cast<const uint4 *>(ab);
-                    a[1].u = *reinterpret_cast<const uint4 *>(ab + 32);
-                } else {
-                    asm volatile("" : "=v"(a[0].r), "=v"(a[1].r) : "v"(ab));
-                }
-            };
-            auto mfma3 = [&](int mt, U (&a)[2]) {
-                if (HX_ABLATE & 4) { asm volatile("" :: "v"(a[0].r), "v"(a[1].r), "v"(b[0].r), "v"(b[1].r)); return; }
-                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1].v, b[0].v, lo[mt], 0, 0, 0);
-                hi[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[0].v, hi[mt], 0, 0, 0);
-                lo[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0].v, b[1].v, lo[mt], 0, 0, 0);
-            };
-            U a0[2], a1[2];
-            a_read(a0, a_ptr(0));
-            a_read(a1, a_ptr(1));
-            mfma3(0, a0);
-            mfma3(1, a1);
-        };
-        __syncthreads();                                   // tile staged (and group gg's weights parked)
-#pragma unroll 1
-        for (int g = 0; g < NG; ++g) {
-            const int gg = ch * NG + g;
-            const uint4 *wb = wbuf + (gg & 1) * GV4 + fragoff;
-#pragma unroll
-            for (int i = 0; i < GROUP; ++i) step(g * GROUP + i, wb + i * SLAB_V4);
-            __builtin_amdgcn_sched_barrier(0);
-            if (gg + 1 < NGT) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // group gg+1 has landed in registers
-                u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + ((gg + 1) & 1) * GV4);
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) dst[tid + i * 512] = wp[i];
-                if (!(HX_ABLATE & 16) && gg + 2 < NGT) issue(gg + 2);
-            }
-            if (g + 1 < NG) __syncthreads();               // (the chunk loop's barriers cover the last group)
-        }
-    }
-    // ---- combine the two accumulators; COUT = 32: add the other tap-half's partial sums --------
-    f32x16 res[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) res[mt][e] = hi[mt][e] + lo[mt][e] * (1.0f / HX_LSCALE);
-    if constexpr (NT == 1) {
-        // role r finalises M-tile r: it hands its partial of tile 1-r to the partner wave (wid ^ 4)
-        float *xb = reinterpret_cast<float *>(in_lds);
-        __syncthreads();                                  // everyone is done reading the input tile
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xb[(wid * 16 + e) * 64 + lane] = role == 0 ? res[1][e] : res[0][e];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float o = xb[((wid ^ 4) * 16 + e) * 64 + lane];
-            if (role == 0) res[0][e] += o; else res[1][e] = o + res[1][e];     // tap-half 0 + tap-half 1
-        }
-    }
-    // ---- epilogue: BN + sigmoid per lane (lane = output channel), then the wave's 32 x 32 tile is
-    // turned through a wave-private LDS patch ([row][36]) so that a lane owns 4 consecutive channels
-    // of a position: shortcut loads and output stores are 16 bytes per lane (4 x 1 KB per tile
-    // instead of 16 x 256 B), same arithmetic in the same order.
-    __syncthreads();                                      // input tile / exchange buffer no longer read
-    float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
-    const int jb = cout_off + (NT == 1 ? 0 : role * 32);
-    const int j = jb + (lane & 31);
-    const int c4 = (lane & 7) * 4;
-    const float out_scale = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
-    const float s1 = p.s1[j] * out_scale, t1 = p.t1[j];
-    float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + jb + c4);
-    if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + jb + c4);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        if (NT == 1 && mt != role) continue;
-        if (HX_ABLATE & 2) { if (res[mt][0] == 123.456f) p.out[tid] = res[mt][1]; continue; }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            tb[row * HX_TPITCH + (lane & 31)] = sigmoidf_(res[mt][e] * s1 + t1);
-        }
-        int spq[4], gwq[4];
-        float4 scv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = pg * 64 + mt * 32 + (lane >> 3) + 8 * i;
-            spq[i] = pos_sp[q];
-            gwq[i] = pos_win[q];
-        }
-        if (p.sc) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float *scp = p.sc + (size_t)gwq[i] * p.sc_win_stride + (size_t)max(spq[i], 0) * p.cout_total + jb + c4;
-                scv[i] = (spq[i] >= 0 && !(HX_ABLATE & 1024)) ? *reinterpret_cast<const float4 *>(scp)
-                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
-            if (spq[i] < 0) continue;
-            if (p.sc) {
-                v.x = (v.x + scv[i].x) * s2v.x + t2v.x;
-                v.y = (v.y + scv[i].y) * s2v.y + t2v.y;
-                v.z = (v.z + scv[i].z) * s2v.z + t2v.z;
-                v.w = (v.w + scv[i].w) * s2v.w + t2v.w;
-            }
-            float *o = p.out + (size_t)gwq[i] * p.out_win_stride + (size_t)spq[i] * p.cout_total + jb + c4;
-            if (!(HX_ABLATE & 512) || v.x == 123.456f) *reinterpret_cast<float4 *>(o) = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// COUT = 32 form: one 32-position M-tile per wave, every tap, software-pipelined fragments.
+// One 32-position M-tile and 32 output channels per wave, every tap.
 //
 // In conv_f16x3_kernel a wave holds four accumulators (two M-tiles x hi/lo = 64 VGPRs), which
 // leaves hipcc one fragment register set: it reads an A fragment, waits, issues one or two
@@ -392,7 +96,10 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3_kernel(ConvParams p, const 
 // geometry, staging, weight groups (8 taps = 16 KB) and epilogue.  A B fragment now feeds one
 // tile instead of two: 4 reads per 3 MFMAs, still well inside the LDS rate.
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN>
+// MASKED = true is the small-image form: whole H x W <= 64 images of several windows per workgroup,
+// no halo in LDS; every tap's A-fragment address is chosen per lane (in-bounds neighbour or one
+// all-zero position), so the "same" padding costs no LDS.
+template <int KH, int KW, int CIN, bool MASKED>
 __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const uint4 *__restrict__ w16s,
                                                              HxScale hs) {
     constexpr int NCHUNK = CIN / BX_CC;
@@ -416,8 +123,8 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int THin = p.TH + KH - 1, TWin = p.TW + KW - 1;
-    const int RP = bx_row_pitch(p.TW, TWin);
+    const int THin = MASKED ? p.TH : p.TH + KH - 1, TWin = MASKED ? p.TW : p.TW + KW - 1;
+    const int RP = MASKED ? p.TW : bx_row_pitch(p.TW, TWin);
     const int cout_off = blockIdx.y * 32;
     const uint4 *w16 = w16s + (size_t)blockIdx.y * ((size_t)NCHUNK * NSLAB * SLAB_V4);
     int bid;
@@ -454,14 +161,19 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     // together (0-3,12-15,20-27 ...) read 16 distinct slots or the same address: conflict-free.  Two 16-position M-subtiles x two 16-channel
     // N-subtiles x (hi, lo) = eight 4-register accumulators.
     int abase[2];
+    unsigned lrc = 0;                                      // MASKED: (row, col) of both M-subtiles, 8 bits each
+    const int tsel = (lane >> 4) & 1;                      // this lane's tap of a tap pair
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
         int q = wid * 32 + ms * 16 + (lane & 15);
         int w_ = q / ptile, rem = q - w_ * ptile;
         int r = rem / p.TW, c = rem - r * p.TW;
         if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
-        abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16 + ((lane >> 4) & 1) * HX_PSTRIDE;
+        abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16 + (MASKED ? 0 : tsel * HX_PSTRIDE);
+        lrc |= ((unsigned)r | ((unsigned)c << 8)) << (16 * ms);
     }
+    const int zero_off = p.NWIN * THin * RP * HX_PSTRIDE + (lane >> 5) * 16;
+    if (MASKED && tid < 20) reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
     f32x4 hi[2][2], lo[2][2];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
@@ -491,7 +203,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             const int cg = it & 1, pc = it >> 1;
             const int wr = pc / TWin, ci = pc - wr * TWin;
             const int w_ = wr / THin, ri = wr - w_ * THin;
-            const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
+            const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
             sdst[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
             if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W)
                 ssrc[u] = p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + cg * 8;
@@ -523,7 +235,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         }
     };
     issue(0);                                             // first weight group: lands while the first tile is staged
-    stage_issue(0);
+    if constexpr (!MASKED) stage_issue(0);                 // (masked tiles are small: staged synchronously, registers saved)
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
         // ---- stage + split the input tile (16 channels).  The first pass (two items per thread) was
@@ -531,6 +243,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         // the previous chunk, so its latency runs under that group's MFMAs. ------------------------
         // chunk 0: wait here; later chunks: the values landed with the wait that closed the previous
         // chunk's last weight group (waiting again would expose the weight loads issued since)
+        if constexpr (!MASKED) {
         if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < HXS_NIT; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
@@ -542,11 +255,12 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             for (int e = 0; e < 8; ++e) v[e] = ssrc[u] ? __uint_as_float(sv[u][e >> 2][e & 3]) : 0.f;
             split_store(v, sdst[u]);
         }
-        for (int it = HXS_NIT * 512 + tid; it < items; it += 512) { // tiles with more than 1536 items
+        }
+        for (int it = (MASKED ? 0 : HXS_NIT * 512) + tid; it < items; it += 512) { // masked tiles; items beyond the prefetch slots
             const int cg = it & 1, pc = it >> 1;
             const int wr = pc / TWin, ci = pc - wr * TWin;
             const int w_ = wr / THin, ri = wr - w_ * THin;
-            const int gr = r0 + ri - PAD_T, gc = c0 + ci - PAD_L, gw = win0 + w_;
+            const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
                 const float4 *src = reinterpret_cast<const float4 *>(
@@ -573,7 +287,15 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             auto loadA = [&](int tp, int ms) {
                 const int tap = g * GT + 2 * tp;
                 const int dy = tap / KW, dx = tap - dy * KW;
-                const char *ap = in_lds + abase[ms] + (dy * RP + dx) * HX_PSTRIDE;
+                const char *ap;
+                if constexpr (MASKED) {
+                    const int rr = (int)((lrc >> (16 * ms)) & 255u) + dy - PAD_T;
+                    const int cc = (int)((lrc >> (16 * ms + 8)) & 255u) + dx + tsel - PAD_L;
+                    const bool inb = (unsigned)rr < (unsigned)p.H && (unsigned)cc < (unsigned)p.W;
+                    ap = in_lds + (inb ? abase[ms] + ((dy - PAD_T) * RP + (dx + tsel - PAD_L)) * HX_PSTRIDE : zero_off);
+                } else {
+                    ap = in_lds + abase[ms] + (dy * RP + dx) * HX_PSTRIDE;
+                }
                 a[0].u = *reinterpret_cast<const uint4 *>(ap);
                 a[1].u = *reinterpret_cast<const uint4 *>(ap + 32);
             };
@@ -586,7 +308,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 }
             };
             // next chunk's tile: loads fly under this (last) group's matrix work
-            if (g == NG - 1 && ch + 1 < NCHUNK) stage_issue(ch + 1);
+            if constexpr (!MASKED) if (g == NG - 1 && ch + 1 < NCHUNK) stage_issue(ch + 1);
 #pragma unroll
             for (int tp = 0; tp < GT / 2; ++tp) {
 #pragma unroll

@@ -902,7 +902,6 @@ struct ConvOp {
     bool masked16 = false;
     double eff32 = 0, eff16 = 0;
     // split-fp16 variant (null when not built for this layer); N-slicing as for split-bf16
-    uint4 *wh = nullptr;
     uint4 *whs = nullptr;      // 32-wide N-slices: 16x16x32 fragments of tap pairs (conv_f16x3s_kernel)
     int nsliceh = 1, cwh = 0;  // split-fp16 N-slicing: 32-wide slices unless the layer runs the masked form
     int THh = 0, TWh = 0, NWINh = 1;
@@ -1109,27 +1108,9 @@ static void choose_tile_h(ConvOp &c) {
     }
 }
 
-template <int KH, int KW, int CIN, int COUT, bool MASKED>
-static int launch_convh_t(const ConvOp &c, ConvParams p, const float *xmax, hipStream_t st) {
-    auto kern = conv_f16x3_kernel<KH, KW, CIN, COUT, MASKED>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
-        attr_set = true;
-    }
-    p.TH = c.THh; p.TW = c.TWh; p.NWIN = c.NWINh;
-    p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
-    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
-    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
-    HxScale hs{xmax, c.alpha, c.beta, c.sw};
-    kern<<<dim3(grid, c.nsliceh), 512, c.ldsh, st>>>(p, c.wh, hs);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
-}
-template <int KH, int KW, int CIN>
+template <int KH, int KW, int CIN, bool MASKED>
 static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipStream_t st) {
-    auto kern = conv_f16x3s_kernel<KH, KW, CIN>;
+    auto kern = conv_f16x3s_kernel<KH, KW, CIN, MASKED>;
     static bool attr_set = false;
     if (!attr_set) {
         AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1147,18 +1128,13 @@ static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipS
 }
 template <int KH, int KW>
 static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
-    // non-masked layers: 32-wide N-slices on the single-tile kernel; small images: the masked form
-    if (!c.maskedh) {
-        if (!c.whs || c.cwh != 32) return AMT_E_UNSUPPORTED;
-        if (c.cin == 32) return launch_convs_t<KH, KW, 32>(c, p, xmax, st);
-        if (c.cin == 64) return launch_convs_t<KH, KW, 64>(c, p, xmax, st);
-        if (c.cin == 128) return launch_convs_t<KH, KW, 128>(c, p, xmax, st);
-        return AMT_E_UNSUPPORTED;
-    }
-#define HX_CASE(CI, CO)                                                                    \
-    if (c.cin == CI && c.cwh == CO) return launch_convh_t<KH, KW, CI, CO, true>(c, p, xmax, st);
-    HX_CASE(32, 32) HX_CASE(32, 64) HX_CASE(64, 64) HX_CASE(128, 64)
-#undef HX_CASE
+    // every layer runs 32-wide N-slices (blockIdx.y) of the single-tile kernel; small images its masked form
+    if (!c.whs || c.cwh != 32) return AMT_E_UNSUPPORTED;
+#define HXS_CASE(CI)                                                                       \
+    if (c.cin == CI) return c.maskedh ? launch_convs_t<KH, KW, CI, true>(c, p, xmax, st)   \
+                                      : launch_convs_t<KH, KW, CI, false>(c, p, xmax, st);
+    HXS_CASE(32) HXS_CASE(64) HXS_CASE(128)
+#undef HXS_CASE
     return AMT_E_UNSUPPORTED;
 }
 static int launch_convh(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
@@ -1361,13 +1337,9 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         }
                         c.w16 = static_cast<uint4 *>(d16);
                     }
-                    // split-fp16 weights: [slice][chunk16][slab][tt][plane(2)][nt][h][col][8] f16, scaled 2^sw
-                    c.nsliceh = c.nslice16; c.cwh = c.cw16;
+                    // split-fp16 weights, scaled 2^sw (layout below)
+                    c.cwh = 32; c.nsliceh = fo / 32;                   // 32-wide N-slices
                     choose_tile_h(c);
-                    if (!c.maskedh) {                                      // large images: 32-wide N-slices
-                        c.cwh = 32; c.nsliceh = fo / 32;
-                        choose_tile_h(c);
-                    }
                     float wmax = 0.f;
                     bool finite = std::isfinite(c.alpha) && std::isfinite(c.beta);
                     for (size_t q = 0; q < (size_t)ntap * C * fo; ++q) {
@@ -1379,38 +1351,8 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                         (void)frexpf(wmax, &ew);                          // wmax < 2^ew
                         c.sw = 4 - ew;                                     // max |w| 2^sw in [8, 16)
                         const float wscale = ldexpf(1.0f, c.sw);
-                        const int NT16 = c.cwh / 32;
-                        const int tps = NT16 == 1 ? 2 : 1;
-                        const int nslab = ntap / tps;
                         const int nch16 = C / BX_CC;
-                        std::vector<unsigned short> whv((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
-                        for (int sl = 0; sl < c.nsliceh; ++sl)
-                            for (int ch = 0; ch < nch16; ++ch)
-                                for (int sb = 0; sb < nslab; ++sb)
-                                    for (int tt = 0; tt < tps; ++tt)
-                                        for (int nt = 0; nt < NT16; ++nt)
-                                            for (int h = 0; h < 2; ++h)
-                                                for (int col = 0; col < 32; ++col)
-                                                    for (int jj = 0; jj < 8; ++jj) {
-                                                        const int tap = sb * tps + tt;
-                                                        const int cin_i = ch * BX_CC + 8 * h + jj;
-                                                        const float wv = kern[((size_t)tap * C + cin_i) * fo + sl * c.cwh + nt * 32 + col];
-                                                        unsigned short hh[2];
-                                                        amt_split_f16<true>(wv * wscale, hh[0], hh[1]);
-                                                        for (int pl = 0; pl < 2; ++pl) {
-                                                            const size_t idx =
-                                                                ((((((((size_t)sl * nch16 + ch) * nslab + sb) * tps + tt) * 2 + pl) * NT16 + nt) * 2 + h) * 32 + col) * 8 + jj;
-                                                            whv[idx] = hh[pl];
-                                                        }
-                                                    }
-                        void *dh = nullptr;
-                        if (hipMalloc(&dh, whv.size() * 2) != hipSuccess) { amt_rdcnn_destroy(n); return AMT_E_NOMEM; }
-                        n->allocs.push_back(static_cast<float *>(dh));
-                        if (hipMemcpy(dh, whv.data(), whv.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
-                            amt_rdcnn_destroy(n); return AMT_E_HIP;
-                        }
-                        c.wh = static_cast<uint4 *>(dh);
-                        if (c.cwh == 32 && !c.maskedh) {
+                        if (c.cwh == 32) {
                             // [slice][chunk16][tap pair][plane][N-subtile][lane = col + 16 kgroup][8] f16:
                             // kgroup g = (tap 2 tp + g % 2, channels 8 (g / 2) .. + 7)
                             std::vector<unsigned short> ws((size_t)nch16 * ntap * 2 * NT * 2 * 32 * 8);
@@ -1636,7 +1578,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                 const float *sc = nullptr; size_t sc_stride = 0;
                 const ProjOp *rank1 = nullptr;
                 if (c.residual) {
-                    if (c.sc_proj >= 0 && net->mode == 2 && c.wh && !c.maskedh && tw.projs[c.sc_proj].cin == 1 &&
+                    if (c.sc_proj >= 0 && net->mode == 2 && c.whs && !c.maskedh && tw.projs[c.sc_proj].cin == 1 &&
                         tw.projs[c.sc_proj].ph == 1 && tw.projs[c.sc_proj].pw == 1 && tw.projs[c.sc_proj].w) {
                         rank1 = &tw.projs[c.sc_proj];                 // formed in the consumer's epilogue
                     } else if (c.sc_proj >= 0) {
@@ -1692,7 +1634,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         cp.sc1 = p0; cp.sc1_win_stride = p0_stride;
                         cp.sc1_w = rank1->w; cp.sc1_s = rank1->s; cp.sc1_t = rank1->t;
                     }
-                    const int rc = (net->mode == 2 && c.wh) ? launch_convh(c, cp, xmax + t, st)
+                    const int rc = (net->mode == 2 && c.whs) ? launch_convh(c, cp, xmax + t, st)
                                    : (net->mode >= 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
                 }

@@ -128,7 +128,7 @@ def test_split_bf16_kernels_are_spill_free():
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if not any(k in name for k in ('conv_bf16x6_kernel', 'conv_f16x3_kernel', 'conv_f16x3s_kernel')):
+        if not any(k in name for k in ('conv_bf16x6_kernel', 'conv_f16x3s_kernel')):
             continue
         seen += 1
         spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
@@ -136,4 +136,4 @@ def test_split_bf16_kernels_are_spill_free():
         vgpr = int(re.search(r'\bVGPRs: (\d+)', b).group(1))
         assert spill == 0 and scratch == 0, (name, spill, scratch)
         assert vgpr <= 128, (name, vgpr)          # 4 waves per SIMD = two workgroups per CU
-    assert seen >= 21
+    assert seen >= 24 + 18
