@@ -61,10 +61,16 @@ def transcribe(wf, params=None, iters=5, heads=('timing', 'pitch', 'instrument',
         loop.setup_device()
     L = p.H * (p.timing_frames - 1)
     wins, starts = cut_windows(np.asarray(wf, dtype=np.float32), L, L // 2)
+    # song-level normalisers (training.py:269-282 computes ref_mag / ref_C_* once per song): the maxima
+    # over the windows of the first batch, then shared by every window of the song
+    first = torch.from_numpy(wins[:batch]).cuda()
+    loop.prepare(first)
+    song_refs = {k: v.max() for k, v in loop.refs.items()}
     all_ev = []
     for b0 in range(0, len(wins), batch):
-        chunk = torch.from_numpy(wins[b0:b0 + batch]).cuda()
-        e, _ = loop.run(chunk, window0=b0)
+        chunk = first if b0 == 0 else torch.from_numpy(wins[b0:b0 + batch]).cuda()
+        refs = {k: v.expand(chunk.shape[0]).contiguous() for k, v in song_refs.items()}
+        e, _ = loop.run(chunk, window0=b0, refs=refs)
         all_ev.append(e.cpu().numpy())
     evs = np.concatenate(all_ev, axis=1)
     notes = ev.events_to_notes(evs, p.timing_frames, L, sr=p.sr,
