@@ -34,15 +34,16 @@ def test_glue_kernels(env):
         assert np.array_equal(tab[i], slice_C_frames(T, int(s[i]), int(e[i]), 8)), i
 
 
-@pytest.mark.parametrize('heads,iters,seeds', [
-    (('timing', 'pitch', 'velocity'), 2, None),                      # onset 17, end 34: crop to 8 frames
-    (('pitch', 'instrument'), 2, None),                              # no timing heads: frames 0..8
-    (('timing', 'pitch', 'instrument', 'velocity'), 3, {'timing_start': 108}),   # 7 frames: tile rule
-    (('timing', 'pitch'), 1, {'timing_start': 104}),                 # end < onset: empty slice -> zeros
+@pytest.mark.parametrize('heads,iters,seeds,nfft,wsec', [
+    (('timing', 'pitch', 'velocity'), 2, None, 2048, 1),             # onset 17, end 34: crop to 8 frames
+    (('pitch', 'instrument'), 2, None, 2048, 1),                     # no timing heads: frames 0..8
+    (('timing', 'pitch', 'instrument', 'velocity'), 3, {'timing_start': 108}, 2048, 1),   # 7 frames: tile rule
+    (('timing', 'pitch'), 1, {'timing_start': 104}, 2048, 1),        # end < onset: empty slice -> zeros
+    (('timing', 'pitch', 'velocity'), 2, None, 4096, 2),             # the reference's default N = 4096 (F = 2049)
 ])
-def test_loop_vs_oracle(env, heads, iters, seeds):
+def test_loop_vs_oracle(env, heads, iters, seeds, nfft, wsec):
     torch, synth = env['torch'], env['synth']
-    p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)             # 86 frames: oracle-sized
+    p = env['hp'].Hyperparams(N=nfft, window_size_note_time=wsec)          # 86 frames: oracle-sized
     groups = (0, 1, 2) if 'instrument' in heads else (0,)
     lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, seeds=seeds).setup_device()
     L = p.H * (p.timing_frames - 1)
