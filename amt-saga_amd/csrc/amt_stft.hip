@@ -36,7 +36,9 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
     int hop, int center, int pairs_per_block) {
     __shared__ float2 buf[N];
     __shared__ float2 tw[N];
-    __shared__ float red[16];
+    // the reduction scratch aliases the FFT buffer (used once, after the last transform): at
+    // N = 2048 the kernel then needs exactly 32 KB of LDS and FIVE workgroups fit a CU, not four
+    float *red = reinterpret_cast<float *>(buf);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     for (int i = tid; i < N; i += AMT_FFT_THREADS) tw[i] = tw_global[i];
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
         // the next pair's first pass barriers before it overwrites `buf`
     }
     if (ref_max) {
+        __syncthreads();                                 // every wave is done with `buf`
         lmax = block_max(lmax, red);
         if (tid == 0) atomicMax(reinterpret_cast<int *>(ref_max) + b, __float_as_int(lmax));
     }
