@@ -23,10 +23,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math'
          '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 # per-file additions (appended, so they win).  The FFT butterflies and twiddle products of the
-# STFT / iSTFT are tolerance-checked floating point (1e-4 against the oracle): fused multiply-adds
+# STFT / iSTFT and the CQT accumulations are tolerance-checked floating point (1e-4 against the oracle): fused multiply-adds
 # there cost nothing in parity and save ~a quarter of the vector instructions.  Everything that is
 # compared bit for bit (subtract, the conv epilogues, the f32 MFMA chains) keeps contraction off.
-FILE_FLAGS = {'amt_stft.hip': ['-ffp-contract=fast']}
+FILE_FLAGS = {'amt_stft.hip': ['-ffp-contract=fast'], 'amt_cqt.hip': ['-ffp-contract=fast']}
 
 
 def _newer(a, b):

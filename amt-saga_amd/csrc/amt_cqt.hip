@@ -27,11 +27,18 @@
 struct c3 { float r0, i0, rp, ip, rm, im; };
 
 __device__ __forceinline__ void cq_accum(c3 &s, float xv, float c, float sn, float cw, float sw) {
-    // z = x e^{-i phi} = (xv c, -xv sn);  z e^{+i theta u} and z e^{-i theta u}
+    // z = x e^{-i phi} = (xv c, -xv sn).  S+- = sum z e^{+-i theta u} = P +- iQ with the cosine- and
+    // sine-weighted sums P = sum z cos(theta u), Q = sum z sin(theta u): four multiply-adds per
+    // sample instead of eight; (rp, ip) holds P and (rm, im) holds Q until cq_finish().
     const float zr = xv * c, zi = -xv * sn;
     s.r0 += zr; s.i0 += zi;
-    s.rp += zr * cw - zi * sw; s.ip += zr * sw + zi * cw;
-    s.rm += zr * cw + zi * sw; s.im += zi * cw - zr * sw;
+    s.rp += zr * cw; s.ip += zi * cw;
+    s.rm += zr * sw; s.im += zi * sw;
+}
+__device__ __forceinline__ void cq_finish(c3 &s) {        // (P, Q) -> (S+, S-)
+    const float pr = s.rp, pi_ = s.ip, qr = s.rm, qi = s.im;
+    s.rp = pr - qi; s.ip = pi_ + qr;                       // S+ = P + iQ
+    s.rm = pr + qi; s.im = pi_ - qr;                       // S- = P - iQ
 }
 __device__ __forceinline__ void cq_wave_sum(c3 &s) {
     s.r0 = wave_sum(s.r0); s.i0 = wave_sum(s.i0); s.rp = wave_sum(s.rp);
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256) void cqt_slices_kernel(amt_cqt_args a) {
                     const int blk = oj + nb;         // the block behind the frame: its N_k mod H prefix
                     cq_add(s, edgeQ[blk < 7 ? blk : 7 + (blk - nb)]);
                 }
+                cq_finish(s);
                 // C = 1/2 S0 - 1/4 (e^{-i theta o H} S+ + e^{+i theta o H} S-)
                 float sd, cd;
                 sincospif(2.0f * (float)(oj * H) * inv_nk, &sd, &cd);

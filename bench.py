@@ -39,6 +39,10 @@ WORKLOADS = {
                groups=(0,), seed=3,
                name='C3: 1024 polyphonic piano windows, STFT(2048) + pitch+velocity+timing(start,end) '
                     'heads + 1 subtraction iteration'),
+    # per-GPU shard of BASELINE.json configs[3] (4096 windows / 4 GPUs)
+    'c4': dict(B=1024, heads=('pitch', 'instrument'), iters=3, subtract=True, notes=(1, 3),
+               groups=(0, 1, 2), seed=4,
+               name='C4 shard: 1024 mixed-instrument windows per GPU, instrument+pitch heads, 3 iterations'),
     # per-GPU shard of BASELINE.json configs[4] (16384 windows / 8 GPUs)
     'c5': dict(B=2048, heads=('timing', 'pitch', 'instrument', 'velocity'), iters=5, subtract=True,
                notes=(2, 4), groups=(0, 1, 2), seed=5,
