@@ -159,3 +159,26 @@ __device__ __forceinline__ void fft_block(float2 *buf, const float2 *tw, Loader 
         fft_pass<N, 4, 64, INV, false>(buf, tw, none);
     }
 }
+
+// Same schedule with the data already in `buf` (the caller staged it and synchronised).
+template <int N, bool INV>
+__device__ __forceinline__ void fft_block_inplace(float2 *buf, const float2 *tw) {
+    auto none = [](int) { return make_float2(0.f, 0.f); };
+    if constexpr (N == 4096) {
+        fft_pass<N, 8, 1, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 8, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 64, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 512, INV, false>(buf, tw, none);
+    } else if constexpr (N == 2048) {
+        fft_pass<N, 8, 1, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 8, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 64, INV, false>(buf, tw, none);
+        fft_pass<N, 4, 512, INV, false>(buf, tw, none);
+    } else {
+        static_assert(N == 1024, "unsupported FFT size");
+        fft_pass<N, 8, 1, INV, false>(buf, tw, none);
+        fft_pass<N, 8, 8, INV, false>(buf, tw, none);
+        fft_pass<N, 4, 64, INV, false>(buf, tw, none);
+        fft_pass<N, 4, 256, INV, false>(buf, tw, none);
+    }
+}

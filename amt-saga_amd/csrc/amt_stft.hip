@@ -264,15 +264,17 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void istft_stream_kernel(
                 if (k == 0 || k == N / 2) v.y = 0.f;
                 return v;
             };
-            auto load = [&](int n) -> float2 {
-                const bool mirror = n > N / 2;
-                const int k = mirror ? N - n : n;
-                float2 x1 = v0 ? spec(t0, k) : make_float2(0.f, 0.f);
-                float2 x2 = v1 ? spec(t0 + 1, k) : make_float2(0.f, 0.f);
-                if (mirror) { x1.y = -x1.y; x2.y = -x2.y; }
-                return make_float2(x1.x - x2.y, x1.y + x2.x);   // x1 + i*x2
-            };
-            fft_block<N, true>(buf, tw, load);
+            // the packed spectrum Z = X1 + i X2 and its Hermitian half are staged in LDS from ONE read of
+            // every bin (a loader-per-element first pass would fetch each bin twice: direct and mirrored)
+            __syncthreads();                                 // the previous pair's overlap-add is done with `buf`
+            for (int k = tid; k <= N / 2; k += AMT_FFT_THREADS) {
+                const float2 x1 = v0 ? spec(t0, k) : make_float2(0.f, 0.f);
+                const float2 x2 = v1 ? spec(t0 + 1, k) : make_float2(0.f, 0.f);
+                buf[k] = make_float2(x1.x - x2.y, x1.y + x2.x);                  // x1 + i x2
+                if (k > 0 && k < N / 2) buf[N - k] = make_float2(x1.x + x2.y, x2.x - x1.y);   // conj(x1) + i conj(x2)
+            }
+            __syncthreads();
+            fft_block_inplace<N, true>(buf, tw);
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
