@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256) void cqt_slices_kernel(amt_cqt_args a) {
         for (int blk = wid; blk < nblk; blk += 4) {  // one wave per H-sample block
             const bool edge = blk < 7 || blk >= nb;  // wave-uniform
             c3 p{0, 0, 0, 0, 0, 0}, q{0, 0, 0, 0, 0, 0};
+            const int mb = a_min + blk * H;                      // first sample of the block
+            if (!edge && mb >= 0 && mb + H <= a.L) {
+                // interior core block (the bulk of the work): no per-sample bounds test, no branches
+                const float *xb = x + mb;
+                for (int i = lane; i < H; i += 64) {
+                    const float xv = xb[i];
+                    const float turns = (float)((unsigned int)(mb + i) * inc) * 2.3283064365386963e-10f;
+                    const float sn = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
+                    const float wt = (float)(blk * H + i) * inv_nk;
+                    const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
+                    cq_accum(core, xv, c, sn, cw, sw);
+                }
+                continue;
+            }
             for (int i = lane; i < H; i += 64) {
                 const int u = blk * H + i;
                 const int m = a_min + u;
