@@ -99,13 +99,19 @@ __global__ __launch_bounds__(256) void cqt_slices_kernel(amt_cqt_args a) {
             if (!edge && mb >= 0 && mb + H <= a.L) {
                 // interior core block (the bulk of the work): no per-sample bounds test, no branches
                 const float *xb = x + mb;
-                for (int i = lane; i < H; i += 64) {
+                auto body = [&](int i) {
                     const float xv = xb[i];
                     const float turns = (float)((unsigned int)(mb + i) * inc) * 2.3283064365386963e-10f;
                     const float sn = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
                     const float wt = (float)(blk * H + i) * inv_nk;
                     const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
                     cq_accum(core, xv, c, sn, cw, sw);
+                };
+                if (H == 512) {                                  // the hop of the N = 2048 path: fully unrolled
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) body(lane + 64 * j);
+                } else {
+                    for (int i = lane; i < H; i += 64) body(i);
                 }
                 continue;
             }
