@@ -12,7 +12,7 @@ RDCNN heads -> note decision -> guess lookup -> subtract] -> event gather.
 Weak scaling: every rank processes the same number of windows.
 
 Prints ONE JSON line on rank 0 with the driver contract plus
-  roofline      dominant kernel (timing-head conv, fp32 MFMA): achieved TFLOP/s from
+  roofline      dominant kernel (timing-head convolution on the matrix pipe): achieved TFLOP/s from
                 HIP events recorded around every conv launch inside the timed region
   roofline_stft the north-star HBM kernel pair (STFT->mag/phase/max, subtract):
                 algorithmic GB/s from HIP events on the launch stream
@@ -106,7 +106,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1, 2),
-                    help='1 = split-bf16 convolutions (f32-equivalent, default), 0 = f32 MFMA')
+                    help='convolution arithmetic: 2 = split-fp16 (default), 1 = split-bf16, 0 = f32 MFMA; all f32-equivalent')
     args = ap.parse_args()
 
     from amt_saga import dist as adist, synth
