@@ -35,11 +35,11 @@ def test_glue_kernels(env):
 
 
 @pytest.mark.parametrize('heads,iters,seeds,nfft,wsec', [
-    (('timing', 'pitch', 'velocity'), 1, None, 2048, 1),             # onset 17, end 34: crop to 8 frames
-    (('pitch', 'instrument'), 1, None, 2048, 1),                     # no timing heads: frames 0..8
-    (('timing', 'pitch', 'instrument', 'velocity'), 2, {'timing_start': 108}, 2048, 1),   # 7 frames: tile rule
+    (('timing', 'pitch', 'velocity'), 2, None, 2048, 1),             # onset 17, end 34: crop to 8 frames
+    (('pitch', 'instrument'), 2, None, 2048, 1),                     # no timing heads: frames 0..8
+    (('timing', 'pitch', 'instrument', 'velocity'), 3, {'timing_start': 108}, 2048, 1),   # 7 frames: tile rule
     (('timing', 'pitch'), 1, {'timing_start': 104}, 2048, 1),        # end < onset: empty slice -> zeros
-    (('timing', 'pitch', 'velocity'), 1, None, 4096, 2),             # the reference's default N = 4096 (F = 2049)
+    (('timing', 'pitch', 'velocity'), 2, None, 4096, 2),             # the reference's default N = 4096 (F = 2049)
 ])
 def test_loop_vs_oracle(env, heads, iters, seeds, nfft, wsec):
     torch, synth = env['torch'], env['synth']

@@ -57,7 +57,7 @@ def test_synth_argument_checks(env):
 
 @pytest.mark.parametrize('heads,iters,seeds', [
     (('timing', 'pitch', 'velocity'), 2, None),
-    (('timing', 'pitch', 'instrument', 'velocity'), 1, {'timing_start': 108}),
+    (('timing', 'pitch', 'instrument', 'velocity'), 2, {'timing_start': 108}),
 ])
 def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
     torch, synth = env['torch'], env['synth']
