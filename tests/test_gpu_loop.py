@@ -47,7 +47,7 @@ def test_loop_vs_oracle(env, heads, iters, seeds, nfft, wsec):
     groups = (0, 1, 2) if 'instrument' in heads else (0,)
     lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, seeds=seeds).setup_device()
     L = p.H * (p.timing_frames - 1)
-    B = 3
+    B = 5
     wave, _ = synth.make_windows(B, L, seed=21, notes_per_window=(1, 3), groups=groups,
                                  max_onset=0.4, device='cuda')
     events, b = lp.run(wave, window0=100)
@@ -73,7 +73,7 @@ def test_loop_vs_oracle(env, heads, iters, seeds, nfft, wsec):
         mag = b.mag[i].cpu().numpy()[:, :F].T
         assert np.abs(mag - mag_ref).max() / mag_ref.max() < 1e-4
         assert abs(float(b.ref_max[i]) - mag_ref.max()) / mag_ref.max() < 1e-4
-    assert checked >= 2
+    assert checked >= 3
     # song-level constants: the product's prepare() vs the oracle's definition
     r0 = orc.ref_levels(wave[0].cpu().numpy(), lp.ref_frames)
     for k, v in r0.items():
