@@ -145,3 +145,30 @@ def test_oracle_stft_istft_vs_scipy():
         y = oa.istft(D, hop)
         n = min(len(y), L)
         assert np.abs(y[:n] - x[:n]).max() < 1e-4
+
+
+def test_oracle_cqt_known_answers():
+    """oracle.cqt closed-form checks: a stationary sinusoid at a bin's (quantised) centre frequency
+    gives sqrt(N_k) * A / 2 (L1-normalised Hann, scale = True), independent of the frame position and
+    of the phase; the response is linear in amplitude and falls off over neighbouring bins."""
+    from oracle import cqt as ocqt
+    sr, hop = 44100, 512
+    bpo = 24
+    inc, length, freq = ocqt.cqt_table(sr, 27.5 * 2 ** 3, 48, bpo)          # two octaves from A3
+    L = hop * 120
+    n = np.arange(L)
+    for k in (5, 20, 40):
+        fq = float(inc[k]) / 2.0 ** 32 * sr                                  # the quantised frequency
+        for A, ph0 in ((0.7, 0.3), (0.2, 2.0)):
+            x = A * np.cos(2 * np.pi * fq * n / sr + ph0)
+            C = ocqt.cqt_frames(x, [40, 41, 57, 80], inc, length, hop)
+            want = np.sqrt(length[k]) * A / 2.0
+            assert np.abs(C[k] - want).max() / want < 2e-3, (k, C[k], want)   # image term ~ 1/(4 pi Q)
+            assert C[k].std() / want < 1e-3                                   # frame-position independent
+            assert np.argmax(C[:, 0]) == k
+            assert C[k + 4, 0] < 0.05 * C[k, 0] and C[k - 4, 0] < 0.05 * C[k, 0]
+    # frames outside the signal (zero padding) and the -1 marker
+    x = np.cos(2 * np.pi * float(freq[10]) * n / sr)
+    C = ocqt.cqt_frames(x, [-1, 0, 60], inc, length, hop)
+    assert np.all(C[:, 0] == 0)
+    assert C[10, 1] < 0.75 * C[10, 2]                                         # half of the first frame is padding
