@@ -107,45 +107,70 @@ def write_midi(notes, path):
             f.write(b'MTrk' + struct.pack('>I', len(t)) + t)
 
 
+def _read_vlq(buf, i):
+    v = 0
+    while True:
+        b = buf[i]; i += 1
+        v = (v << 7) | (b & 0x7F)
+        if not b & 0x80:
+            return v, i
+
+
 def read_midi(path):
-    """Minimal reader for files written by write_midi (tests / round trips)."""
+    """Standard MIDI File reader for the note content note_sequence.save() / write_midi produce:
+    format 0/1, ticks-per-quarter division, set-tempo meta events (the first tempo applies to the whole
+    file, as in the single-tempo files magenta writes), running status, note-on with velocity 0 as
+    note-off, program changes.  Returns notes sorted by start time (seconds)."""
     data = open(path, 'rb').read()
-    assert data[:4] == b'MThd'
+    if data[:4] != b'MThd':
+        raise ValueError('not a Standard MIDI File')
     _, fmt, ntr, div = struct.unpack('>IHHH', data[4:14])
+    if div & 0x8000:
+        raise ValueError('SMPTE time division is not supported')
     pos = 14
-    notes = []
+    raw_notes = []
+    tempo = None
     for _ in range(ntr):
-        assert data[pos:pos + 4] == b'MTrk'
+        if data[pos:pos + 4] != b'MTrk':
+            raise ValueError('missing MTrk chunk')
         ln = struct.unpack('>I', data[pos + 4:pos + 8])[0]
         trk = data[pos + 8:pos + 8 + ln]
         pos += 8 + ln
-        i, t, prog, open_notes, status = 0, 0, 0, {}, 0
+        i, t, status = 0, 0, 0
+        prog = {}
+        open_notes = {}
         while i < len(trk):
-            d = 0
-            while True:
-                b = trk[i]; i += 1
-                d = (d << 7) | (b & 0x7F)
-                if not b & 0x80:
-                    break
+            d, i = _read_vlq(trk, i)
             t += d
             if trk[i] & 0x80:
                 status = trk[i]; i += 1
-            if status == 0xFF:
-                typ = trk[i]; ln2 = trk[i + 1]; i += 2 + ln2
+            if status == 0xFF:                                   # meta event
+                typ = trk[i]
+                ln2, i = _read_vlq(trk, i + 1)
+                if typ == 0x51 and tempo is None:
+                    tempo = int.from_bytes(trk[i:i + 3], 'big')
+                i += ln2
                 continue
-            hi = status & 0xF0
+            if status in (0xF0, 0xF7):                           # sysex
+                ln2, i = _read_vlq(trk, i)
+                i += ln2
+                continue
+            hi, ch = status & 0xF0, status & 0x0F
             if hi == 0xC0:
-                prog = trk[i]; i += 1
+                prog[ch] = trk[i]; i += 1
+            elif hi == 0xD0:
+                i += 1
             elif hi in (0x90, 0x80):
                 p, v = trk[i], trk[i + 1]; i += 2
                 if hi == 0x90 and v > 0:
-                    open_notes.setdefault(p, []).append((t, v))
-                elif open_notes.get(p):
-                    t0, v0 = open_notes[p].pop(0)           # overlapping same-pitch notes: FIFO
-                    notes.append(dict(pitch=p, program=prog, velocity=v0,
-                                      start=t0 / (div * 1e6 / TEMPO_US_PER_QUARTER),
-                                      end=t / (div * 1e6 / TEMPO_US_PER_QUARTER)))
+                    open_notes.setdefault((ch, p), []).append((t, v))
+                elif open_notes.get((ch, p)):
+                    t0, v0 = open_notes[(ch, p)].pop(0)     # overlapping same-pitch notes: FIFO
+                    raw_notes.append((p, prog.get(ch, 0), v0, t0, t))
             else:
                 i += 2
+    us_per_tick = (tempo if tempo is not None else TEMPO_US_PER_QUARTER) / float(div)
+    notes = [dict(pitch=p, program=pr, velocity=v, start=t0 * us_per_tick * 1e-6, end=t1 * us_per_tick * 1e-6)
+             for p, pr, v, t0, t1 in raw_notes]
     notes.sort(key=lambda n: (n['start'], n['pitch'], n['program']))
     return notes

@@ -11,8 +11,14 @@ the fixtures but left/side, right/side and mid/side are handled for completeness
 Returns integer PCM; load_float scales by 2**-(bps-1) like libsndfile does.
 
 Writer: VERBATIM subframes (valid FLAC, no compression), fixed block size 4096,
-PCM-24 by default like audio_to_flac; STREAMINFO MD5 left zero (= not computed).
+PCM-24 by default like audio_to_flac; STREAMINFO MD5 of the unencoded samples is written.
+
+Integrity: the reader verifies every frame header's CRC-8, every frame's CRC-16 and the
+STREAMINFO MD5 signature of the decoded samples (when the file carries one) and raises
+ValueError on a mismatch -- byte work is proven bit-exact, not assumed.
 """
+import hashlib
+
 import numpy as np
 
 
@@ -117,13 +123,24 @@ def _subframe(br, blocksize, bps):
     return out
 
 
-def decode(path):
-    """Returns (pcm int64 [n_samples, channels], sample_rate, bits_per_sample)."""
+def pcm_md5(pcm, bps):
+    """MD5 of the unencoded audio as STREAMINFO defines it: samples interleaved by channel,
+    little-endian, each sign-extended to a whole number of bytes."""
+    nbytes = (bps + 7) // 8
+    a = np.ascontiguousarray(np.asarray(pcm, dtype=np.int64).reshape(-1))
+    raw = a.astype('<i8').view(np.uint8).reshape(-1, 8)[:, :nbytes]
+    return hashlib.md5(np.ascontiguousarray(raw).tobytes()).digest()
+
+
+def decode(path, verify=True):
+    """Returns (pcm int64 [n_samples, channels], sample_rate, bits_per_sample).
+    verify: check CRC-8 / CRC-16 of every frame and the STREAMINFO MD5 (if non-zero)."""
     data = open(path, 'rb').read()
     if data[:4] != b'fLaC':
         raise ValueError('not a FLAC file')
     pos = 4
     sr = ch = bps = total = None
+    md5 = bytes(16)
     while True:
         hdr = data[pos]
         last, btype = hdr >> 7, hdr & 0x7F
@@ -135,6 +152,7 @@ def decode(path):
             ch = ((v >> 41) & 7) + 1
             bps = ((v >> 36) & 31) + 1
             total = v & ((1 << 36) - 1)
+            md5 = bytes(body[18:34])
         pos += 4 + blen
         if last:
             break
@@ -142,6 +160,7 @@ def decode(path):
     chans = [[] for _ in range(ch)]
     got = 0
     while got < total:
+        frame_start = br.pos >> 3
         sync = br.read(14)
         if sync != 0x3FFE:
             raise ValueError('lost sync at bit %d' % br.pos)
@@ -172,7 +191,10 @@ def decode(path):
             br.read(8)
         elif sr_code in (13, 14):
             br.read(16)
-        br.read(8)                                   # CRC-8
+        hdr_end = br.pos >> 3
+        crc8 = br.read(8)                            # CRC-8 of the frame header
+        if verify and crc8 != _crc8(data[frame_start:hdr_end]):
+            raise ValueError('FLAC frame header CRC-8 mismatch at byte %d' % frame_start)
         fbps = {0: bps, 1: 8, 2: 12, 4: 16, 5: 20, 6: 24}[ss_code]
         if ca < 8:
             subs = [_subframe(br, bs, fbps) for _ in range(ca + 1)]
@@ -190,11 +212,16 @@ def decode(path):
                 mid = (a << 1) | (b & 1)
                 subs = [(mid + b) >> 1, (mid - b) >> 1]
         br.align()
-        br.read(16)                                  # CRC-16
+        body_end = br.pos >> 3
+        crc16 = br.read(16)                          # CRC-16 of the whole frame
+        if verify and crc16 != _crc16(data[frame_start:body_end]):
+            raise ValueError('FLAC frame CRC-16 mismatch at byte %d' % frame_start)
         for c in range(ch):
             chans[c].extend(subs[c])
         got += bs
     pcm = np.array(chans, dtype=np.int64).T[:total]
+    if verify and md5 != bytes(16) and pcm_md5(pcm, bps) != md5:
+        raise ValueError('FLAC STREAMINFO MD5 mismatch: decoded samples differ from the encoded audio')
     return pcm, sr, bps
 
 
@@ -293,7 +320,7 @@ def encode(pcm, path, sr=44100, bps=24, blocksize=4096):
     si += blocksize.to_bytes(2, 'big') * 2
     si += (min(sizes) if sizes else 0).to_bytes(3, 'big') + (max(sizes) if sizes else 0).to_bytes(3, 'big')
     v = (sr << 44) | ((ch - 1) << 41) | ((bps - 1) << 36) | n
-    si += v.to_bytes(8, 'big') + bytes(16)
+    si += v.to_bytes(8, 'big') + pcm_md5(pcm, bps)
     with open(path, 'wb') as f:
         f.write(b'fLaC' + bytes([0x80]) + len(si).to_bytes(3, 'big') + bytes(si))
         for fr in frames:

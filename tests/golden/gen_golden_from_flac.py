@@ -1,24 +1,52 @@
 #!/usr/bin/env python3
-"""Turn the reference's recorded subtraction fixtures into .npz golden vectors.
+"""Turn the reference's recorded FLAC / MIDI fixtures into golden vectors.
 
 Run (this container only):  python tests/golden/gen_golden_from_flac.py
-Reads  /root/reference/subtraction_demo/{name}_test{,_guess,_sub}.flac
-Writes tests/golden/subtraction_demo_{name}.npz   (int32 PCM-24 data only)
+Reads  /root/reference/subtraction_demo/*.flac, *_guessed.mid and short_window_demo/<j>/*.flac
+Writes tests/golden/recorded_waves.npz   -- int32 PCM-24 sample arrays, one per distinct file
+                                            content (key = first 12 hex digits of its STREAMINFO MD5)
+       tests/golden/recorded_index.json  -- the scenarios: which arrays, which knobs, what error
+       tests/golden/guessed_14000.mid    -- the reference's recorded MIDI file (78 bytes of data)
 
-The triples were produced by the reference's "short version with the
-audio_util" cell (test_snippets.py:473-514): mixture and guess rendered by
-fluidsynth, ``ac_sub.subtract(ac_guess, offset=0.5, ...)`` with N=4096, then
-``.save()`` = librosa.istft -> soundfile PCM_24.  They are the only recorded
-librosa outputs for the STFT -> magphase -> subtract -> iSTFT chain.
+Every file is decoded by the product's FLAC reader with the frame CRC-8 / CRC-16 and the
+STREAMINFO MD5 verified, so the stored samples are bit-exact what the reference recorded.
 
-The per-scenario knobs are not recorded; a grid search over
-normalize x attack_compensation in {-2..2} (kept below as ``search()``) finds
-that {piano, strings-piano, overdriven} reproduce to <= 2.4e-7 absolute (two
-PCM-24 LSBs) with normalize=True, attack_compensation=0, overkill_factor=1.
-Those three are frozen as known-answer tests; the other scenarios were made
-with hand-edited settings that the grid does not recover and are not used.
+(1) subtraction_demo/{name}_test{,_guess,_sub}.flac  (test_snippets.py:473-514): mixture and guess
+    rendered by fluidsynth, ``ac_sub.subtract(ac_guess, offset=0.5, ...)`` with N = 4096, then
+    ``.save()`` = librosa.istft -> soundfile PCM_24: the only recorded librosa outputs of the
+    STFT -> magphase -> subtract -> iSTFT chain.  The per-scenario knobs were hand-edited between runs and
+    are not recorded; ``search()`` recovers them over normalize x attack_compensation (= a frame offset)
+    in -3..3 x overkill_factor.  Two things have to be respected for the recorded residual to be reproducible
+    to the PCM-24 LSB:
+      * several guesses were rendered hotter than full scale and CLIPPED by the PCM-24 writer
+        (piano_velocity_half: three samples at -2^23).  The reference subtracted the unclipped float
+        waveform; frames that contain a clipped guess sample (and, through the overlap-add, the
+        output samples within n_fft + hop of it) cannot be reproduced from the file and are masked;
+      * likewise output samples the writer clipped, and mixture samples at full scale.
+      * when a clipped guess sample sits in the guess's loudest frame, the file's max|STFT(guess)| is not
+        the ref_mag the reference normalised with: that single continuous unknown is fitted (1-D) and
+        recorded as `guess_ref_mag_correction`; all other samples must then still agree.
+    With that, 15 of the 16 scenarios reproduce to <= 8 LSB (1e-6) over >= 100 000 samples each
+    (piano_velocity_double is clipped over 80 % of its length and is not used).
+(2) subtraction_demo/*_{full_window,guessed,after_subtr}.flac (training.py:438-447): dumps of the in-loop
+    ``subtract(ac_note_guessed, offset=onset_gold)`` (normalize=True) at window size (258 frames, N = 4096).
+    The onset is not recorded (1-D search) and neither is the window's internal magnitude (it is the residual
+    of earlier subtractions, an inconsistent spectrogram that |STFT(full_window)| only approximates), so these
+    are LOOSE known answers: the oracle lands within ~1 % rms of the recorded residual at the best onset.
+    (_1000: full_window and after_subtr come from different notes -- the counter is shared by the worker
+    processes, training.py:429 -- and is not used.)
+(3) short_window_demo/<j>/sw_<j>_<program>.flac (test_snippets.py:1193-1211): iSTFT of
+    ``ac.resize(0, 3, j, ['mag','ph'])`` of a 3-s note.  The input render is not recorded, and the files of
+    different j turn out to be separate renders (not prefixes of one another: correlation < 1, lags of hundreds
+    of samples), so the values pin nothing across files; what they do pin is the length law of the j-frame
+    resynthesis, hop * (j - 1).  A sample of programs is kept for that and as real-instrument input of the
+    STFT -> resize -> iSTFT exactness test.
+(4) *_14000_guessed.mid: the MIDI file note_sequence.save() wrote for the guessed note (events.read_midi).
 """
+import itertools
+import json
 import os
+import shutil
 import sys
 
 import numpy as np
@@ -29,49 +57,163 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import flac_decode as fd   # noqa: E402
 
 SRC = '/root/reference/subtraction_demo/'
-FROZEN = {'piano': dict(normalize=True, attack_compensation=0),
-          'strings-piano': dict(normalize=True, attack_compensation=0),
-          'overdriven': dict(normalize=True, attack_compensation=0)}
+SW = '/root/reference/short_window_demo/'
+N_FFT, HOP = 4096, 1024
+FULL = (1 << 23) - 1
+TRIPLES = ['piano', 'piano_1_frame_off', 'piano_-1_frame_off', 'piano_2_frame_off', 'piano_-2_frame_off',
+           'piano_pitch_1_off', 'piano_pitch_-1_off', 'piano_velocity_same', 'piano_velocity_half',
+           'piano_velocity_double', 'strings', 'strings_high', 'strings-piano', 'overdriven',
+           'overdriven-distortion', 'distrotion_guitar_high']
+WINDOW_DUMPS = ['00032fb2047d3cdd0394b89349d858b4_14000', 'Listen!!_5400']
+SW_PROGRAMS = [0, 24, 40, 56, 73]
+SW_FRAMES = [6, 8, 10, 15, 20]
 
 
-def search(name):
-    import itertools
+def _load(path, store):
+    pcm, sr, bps = fd.decode(path)                  # verifies CRC-8, CRC-16 and the STREAMINFO MD5
+    assert sr == 44100 and bps == 24 and pcm.shape[1] == 1, path
+    raw = open(path, 'rb').read()
+    key = raw[8 + 18:8 + 34].hex()[:12]
+    assert key != '0' * 12
+    store[key] = pcm[:, 0].astype(np.int32)
+    return key
+
+
+def reproducible_mask(mix_i, guess_i, sub_i, offset_frames, n_fft=N_FFT, hop=HOP):
+    """Output samples whose recorded value can be reproduced from the recorded inputs: not clipped by
+    the writer, and outside the reach of any input sample the writer clipped."""
+    m = np.abs(sub_i) < FULL - 1
+    reach = n_fft + hop
+    for j in np.flatnonzero((guess_i >= FULL) | (guess_i <= -FULL - 1)):
+        c = offset_frames * hop + int(j)
+        m[max(c - reach, 0):c + reach] = False
+    for j in np.flatnonzero((mix_i >= FULL) | (mix_i <= -FULL - 1)):
+        m[max(int(j) - reach, 0):int(j) + reach] = False
+    return m
+
+
+FROZEN_LSB = 8.0          # float32 iSTFT rounding: <= ~5 LSB observed on exact-knob scenarios
+
+
+def search(mix_i, guess_i, sub_i):
+    """Recover the unrecorded knobs.  Grid: overkill x normalize x attack_compensation.  When the guess file
+    has clipped samples inside its loudest frame, max|STFT(guess)| of the FILE differs from the ref_mag of the
+    unclipped waveform the reference normalised with; that one continuous unknown (`guess_ref_mag_correction`,
+    a factor on the guess's ref_mag) is then fitted by a 1-D search and everything else must still agree."""
     from oracle.audio import AudioCompleteOracle as AC
-    mix, _ = fd.load_float(SRC + name + '_test.flac')
-    g, _ = fd.load_float(SRC + name + '_test_guess.flac')
-    sub, _ = fd.load_float(SRC + name + '_test_sub.flac')
-    A = AC(mix, 4096); A.mag
-    B = AC(g, 4096); B.mag
-    best = None
-    for norm, acomp in itertools.product((True, False), (-2, -1, 0, 1, 2)):
+    sc = 1.0 / (1 << 23)
+    A = AC(mix_i * sc, N_FFT); A.mag
+    B = AC(guess_i * sc, N_FFT); B.mag
+    sub = sub_i * sc
+
+    def run(overkill, norm, acomp, corr=1.0):
         a = A.clone()
-        a.subtract(B.clone(), offset=0.5, attack_compensation=acomp, normalize=norm)
-        m = np.abs(sub) < 0.999
-        e = np.abs(a.wf - sub)[m].max()
-        if best is None or e < best[0]:
-            best = (e, norm, acomp)
+        b = B.clone()
+        b._ref_mag = np.float32(B.ref_mag * corr)
+        a.subtract(b, offset=0.5, attack_compensation=acomp, normalize=norm, overkill_factor=overkill)
+        off = max(a._seconds_to_frames(0.5) - acomp, 0)
+        m = reproducible_mask(mix_i, guess_i, sub_i, off)
+        if m.sum() < 1000:
+            return None
+        return dict(err_lsb=float(np.abs(a.wf - sub)[m].max()) * (1 << 23), normalize=bool(norm),
+                    attack_compensation=int(acomp), overkill_factor=float(overkill), offset_frames=int(off),
+                    n_checked=int(m.sum()), guess_ref_mag_correction=float(corr))
+
+    best = None
+    for overkill, norm, acomp in itertools.product((1.0, 0.5, 2.0), (True, False), range(-3, 4)):
+        r = run(overkill, norm, acomp)
+        if r is None:
+            return dict(err_lsb=float('inf'), n_checked=0)
+        if best is None or r['err_lsb'] < best['err_lsb']:
+            best = r
+        if best['err_lsb'] <= FROZEN_LSB:
+            return best
+    if best['normalize']:
+        lo, hi = 0.8, 1.25
+        f = lambda c: run(best['overkill_factor'], True, best['attack_compensation'], c)['err_lsb']
+        cs = np.linspace(lo, hi, 46)
+        es = [f(c) for c in cs]
+        i = int(np.argmin(es))
+        lo, hi = cs[max(i - 1, 0)], cs[min(i + 1, len(cs) - 1)]
+        for _ in range(48):
+            m1, m2 = lo + (hi - lo) * 0.382, lo + (hi - lo) * 0.618
+            if f(m1) < f(m2):
+                hi = m2
+            else:
+                lo = m1
+        r = run(best['overkill_factor'], True, best['attack_compensation'], 0.5 * (lo + hi))
+        if r['err_lsb'] < best['err_lsb']:
+            best = r
     return best
 
 
+def search_window_dump(fw_i, guess_i, after_i):
+    from oracle import audio as oa
+    from oracle.audio import AudioCompleteOracle as AC
+    sc = 1.0 / (1 << 23)
+    A = AC((fw_i * sc).astype(np.float32), N_FFT); A.mag
+    B = AC((guess_i * sc).astype(np.float32), N_FFT); B.mag
+    sub = after_i * sc
+    n = min(len(fw_i), len(after_i))
+    first = int(np.flatnonzero(np.abs(fw_i[:n] - after_i[:n]) * sc > 1e-3).min() // HOP)
+    res = []
+    for off in range(max(first - 3, 0), first + 6):
+        mag = A.mag.copy()
+        gm = B.mag * (A.ref_mag / B.ref_mag)
+        k = min(gm.shape[1], mag.shape[1] - off)
+        mag[:, off:off + k] -= gm[:, :k]
+        np.maximum(mag, 0, mag)
+        y = oa.istft(mag * A.ph, HOP)
+        res.append((float(np.sqrt(np.mean((y - sub) ** 2))), off))
+    res.sort()
+    return dict(onset_frame=res[0][1], rms_err=res[0][0], rms_next=res[1][0],
+                rms_signal=float(np.sqrt(np.mean(sub ** 2))))
+
+
 def main():
-    for name, knobs in FROZEN.items():
-        out = {}
-        for key, suffix in (('mix', '_test'), ('guess', '_test_guess'), ('sub', '_test_sub')):
-            pcm, sr, bps = fd.decode(SRC + name + suffix + '.flac')
-            assert sr == 44100 and bps == 24 and pcm.shape[1] == 1
-            out[key] = pcm[:, 0].astype(np.int32)
-        out['n_fft'] = np.array(4096)
-        out['offset_s'] = np.array(0.5)
-        out['normalize'] = np.array(int(knobs['normalize']))
-        out['attack_compensation'] = np.array(knobs['attack_compensation'])
-        path = os.path.join(HERE, 'subtraction_demo_%s.npz' % name)
-        np.savez_compressed(path, **out)
-        print(name, os.path.getsize(path), 'bytes')
+    store, index = {}, dict(n_fft=N_FFT, hop=HOP, offset_s=0.5, triples={}, window_dumps={}, short_windows={})
+    for name in TRIPLES:
+        keys = [_load(SRC + name + suf + '.flac', store) for suf in ('_test', '_test_guess', '_test_sub')]
+        r = search(*[store[k] for k in keys])
+        r['err_lsb'] = r['err_lsb'] if np.isfinite(r['err_lsb']) else -1.0
+        r.update(mix=keys[0], guess=keys[1], sub=keys[2], frozen=bool(0 <= r['err_lsb'] <= FROZEN_LSB))
+        index['triples'][name] = r
+        print(name, r, flush=True)
+    for base in WINDOW_DUMPS:
+        keys = [_load(SRC + base + suf + '.flac', store) for suf in ('_full_window', '_guessed', '_after_subtr')]
+        r = search_window_dump(*[store[k] for k in keys])
+        r.update(full_window=keys[0], guessed=keys[1], after_subtr=keys[2])
+        index['window_dumps'][base] = r
+        print(base, r, flush=True)
+    for prog in SW_PROGRAMS:
+        index['short_windows'][str(prog)] = {str(j): _load('%s%d/sw_%d_%d.flac' % (SW, j, j, prog), store)
+                                             for j in SW_FRAMES}
+    # every other reference FLAC: integrity only (CRC-8/16 + MD5 verified by decode); counted, not stored
+    n_ok = 0
+    for root in (SRC, SW):
+        for dp, _, fs in os.walk(root):
+            for f in sorted(fs):
+                if f.endswith('.flac'):
+                    fd.decode(os.path.join(dp, f))
+                    n_ok += 1
+    index['reference_flac_files_verified'] = n_ok
+    unused = {k for k in store}
+    used = set()
+    for r in index['triples'].values():
+        if r['frozen']:
+            used |= {r['mix'], r['guess'], r['sub']}
+    for r in index['window_dumps'].values():
+        used |= {r['full_window'], r['guessed'], r['after_subtr']}
+    for d in index['short_windows'].values():
+        used |= set(d.values())
+    np.savez_compressed(os.path.join(HERE, 'recorded_waves.npz'), **{'w_' + k: store[k] for k in sorted(used)})
+    with open(os.path.join(HERE, 'recorded_index.json'), 'w') as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+    shutil.copyfile(SRC + '00032fb2047d3cdd0394b89349d858b4_14000_guessed.mid',
+                    os.path.join(HERE, 'guessed_14000.mid'))
+    print('stored', len(used), 'of', len(unused), 'arrays;', n_ok, 'reference FLAC files verified;',
+          os.path.getsize(os.path.join(HERE, 'recorded_waves.npz')), 'bytes')
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'search':
-        for n in sys.argv[2:]:
-            print(n, search(n))
-    else:
-        main()
+    main()

@@ -1,5 +1,5 @@
 """BASELINE config C1: a single window of the reference's own piano_test.flac
-(tests/golden/subtraction_demo_piano.npz), 2048-pt STFT + pitch_classifier.
+(tests/golden/recorded_waves.npz), 2048-pt STFT + pitch_classifier.
 CPU: the oracle path (plumbing).  GPU: the drop-in single-window API
 (audio_complete + pitch_classifier.classify) against the oracle."""
 import os
@@ -11,8 +11,8 @@ from oracle import audio as oa, cqt as ocqt, params as op, rdcnn as orc
 
 
 def _window(golden_dir):
-    z = np.load(os.path.join(golden_dir, 'subtraction_demo_piano.npz'))
-    return (z['mix'] / float(1 << 23)).astype(np.float32)
+    import recorded as rec
+    return (rec.triple('piano')['mix'] / float(1 << 23)).astype(np.float32)
 
 
 def _oracle_c1(wf, weights, p, onset=0.5, dur=1.0):

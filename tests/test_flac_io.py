@@ -39,10 +39,38 @@ def test_float_helpers_and_dropin(tmp_path):
 def test_decoder_matches_committed_fixture(golden_dir):
     """The fixtures in tests/golden were decoded from the reference's FLAC files with this
     same decoder; re-encoding them (verbatim) and decoding again must reproduce the PCM."""
-    z = np.load(os.path.join(golden_dir, 'subtraction_demo_piano.npz'))
+    import recorded as rec
     import tempfile
+    g = rec.triple('piano')['guess']
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, 'g.flac')
-        flac.encode(z['guess'][:20000], p, bps=24)
+        flac.encode(g[:20000], p, bps=24)
         got, sr, bps = flac.decode(p)
-        assert np.array_equal(got[:, 0], z['guess'][:20000])
+        assert np.array_equal(got[:, 0], g[:20000])
+
+
+def test_integrity_checks(tmp_path):
+    """The reader proves byte work bit-exact: a flipped payload bit fails the frame CRC-16, a flipped header
+    bit the CRC-8, and samples that decode but differ from the encoded audio fail the STREAMINFO MD5."""
+    rng = np.random.default_rng(1)
+    pcm = rng.integers(-(1 << 23), 1 << 23, size=(9000, 1))
+    path = str(tmp_path / 'x.flac')
+    flac.encode(pcm, path, bps=24)
+    raw = bytearray(open(path, 'rb').read())
+    assert raw[8 + 18:8 + 34] == flac.pcm_md5(pcm, 24) != bytes(16)
+    flac.decode(path)
+    bad = bytearray(raw); bad[200] ^= 0x10                     # inside the first frame's samples
+    open(path, 'wb').write(bad)
+    with pytest.raises(ValueError, match='CRC-16'):
+        flac.decode(path)
+    got, _, _ = flac.decode(path, verify=False)
+    assert not np.array_equal(got, pcm)
+    first = 4 + 4 + 34                                         # fLaC + block header + STREAMINFO
+    bad = bytearray(raw); bad[first + 3] ^= 0x02               # channel/sample-size byte of the frame header
+    open(path, 'wb').write(bad)
+    with pytest.raises(ValueError, match='CRC-8'):
+        flac.decode(path)
+    bad = bytearray(raw); bad[8 + 20] ^= 0xFF                  # the stored MD5 itself
+    open(path, 'wb').write(bad)
+    with pytest.raises(ValueError, match='MD5'):
+        flac.decode(path)

@@ -200,22 +200,52 @@ def test_subtract_batched_bank(mods):
         assert float(b.ref_max[i]) == exp.max()
 
 
-@pytest.mark.parametrize('name', ['piano', 'strings-piano', 'overdriven'])
-def test_flac_triples_through_hip(mods, golden_dir, name):
-    """The reference's recorded librosa outputs (subtraction_demo) through the HIP
-    chain STFT -> subtract -> iSTFT: within PCM-24 quantisation + fp32 FFT error."""
+import recorded as rec      # noqa: E402  (tests/recorded.py)
+
+
+@pytest.mark.parametrize('name', rec.frozen_triples())
+def test_flac_triples_through_hip(mods, name):
+    """The reference's recorded librosa outputs (subtraction_demo, 15 scenarios) through the HIP chain
+    STFT -> subtract -> iSTFT of the drop-in audio_complete: within fp32 FFT error of the recording on every
+    sample the recorded inputs determine."""
     audio, oa = mods
-    z = np.load(os.path.join(golden_dir, 'subtraction_demo_%s.npz' % name))
-    sc = 1.0 / (1 << 23)
-    mix, guess, sub = z['mix'] * sc, z['guess'] * sc, z['sub'] * sc
-    a = audio.audio_complete(mix, int(z['n_fft']))
-    g = audio.audio_complete(guess, int(z['n_fft']))
-    a.subtract(g, offset=float(z['offset_s']), attack_compensation=int(z['attack_compensation']),
-               normalize=bool(z['normalize']))
-    y = a.wf
-    assert y.shape == sub.shape
-    m = np.abs(sub) < 0.999            # the recorded file clips at +-1.0
+    y, sub, m, z = rec.run_triple(audio.audio_complete, name)
+    assert y.shape == sub.shape and m.sum() >= 100000
     assert np.abs(y - sub)[m].max() < 2e-5
+
+
+@pytest.mark.parametrize('prog', sorted(rec.index()['short_windows']))
+def test_short_window_demo_through_hip(mods, prog):
+    """short_window_demo recordings: STFT -> audio_complete.resize(j, ['mag','ph']) -> iSTFT on the device
+    returns the first hop * (j - 1) samples of the recording it was cut from (see test_oracle_golden)."""
+    audio, oa = mods
+    d = rec.index()['short_windows'][prog]
+    x20 = (rec.wave(d['20']) * rec.SCALE).astype(np.float32)
+    for j in (6, 8, 10, 15, 20):
+        ac = audio.audio_complete(x20, 4096)
+        sw = ac.resize(0.0, len(x20) / 44100.0, j, attribs=['mag', 'ph'])
+        assert sw.shape == (2049, j)
+        y = sw.wf
+        assert y.shape == (1024 * (j - 1),) == rec.wave(d[str(j)]).shape
+        assert np.abs(y - x20[:len(y)]).max() < 2e-5
+
+
+@pytest.mark.parametrize('base', sorted(rec.index()['window_dumps']))
+def test_window_dumps_through_hip(mods, base):
+    """The in-loop subtract(normalize=True) dumps of training.py:438-447 (258 frames, N = 4096) through the HIP
+    chain: same loose bound as the oracle test, and equal to the oracle to 1e-4."""
+    audio, oa = mods
+    r = rec.index()['window_dumps'][base]
+    fw, g, af = (rec.wave(r[k]) * rec.SCALE for k in ('full_window', 'guessed', 'after_subtr'))
+    outs = []
+    for AC in (audio.audio_complete, oa.AudioCompleteOracle):
+        A = AC(fw.astype(np.float32), 4096)
+        G = AC(g.astype(np.float32), 4096)
+        A.subtract(G, offset=A._frames_to_seconds(r['onset_frame']) + 1e-6)
+        outs.append(np.asarray(A.wf))
+    rms = lambda v: float(np.sqrt(np.mean(v ** 2)))
+    assert rms(outs[0] - af) < 0.02 * rms(af)
+    assert np.abs(outs[0] - outs[1]).max() < 1e-4 * np.abs(outs[1]).max()
 
 
 def test_compress_bands_and_short_window(mods, refvec):

@@ -69,17 +69,20 @@ def test_batchnorm_pool_dense():
         assert np.abs(orc.pool2d(x, pool, 'avg') - _n(F.avg_pool2d(_t(x), pool))).max() < 1e-6
 
 
-def _forward_torch(w, cfg, xs):
-    """The graph of RDCNN.py:176-233 written with torch.nn.functional."""
-    tw = {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}
+def _forward_torch(w, cfg, xs, dtype=torch.float32):
+    """The graph of RDCNN.py:176-233 written with torch.nn.functional (any tower count, the
+    1x1-conv + avg-pool + BN shortcut projection of RDCNN.py:312-335 included)."""
+    ndt = np.float32 if dtype == torch.float32 else np.float64
+    tw = {k: torch.from_numpy(np.asarray(v, ndt)) for k, v in w.items()}
 
     def bn(x, p):
         return F.batch_norm(x, tw[p + '/mean'], tw[p + '/var'], tw[p + '/gamma'], tw[p + '/beta'], False, 0.0, 1e-3)
 
     flats = []
     rfreq = cfg['residual_layer_frequencies']
+    n_proj = 0
     for t, x in enumerate(xs):
-        p1 = _t(np.asarray(x, np.float32))
+        p1 = _t(np.asarray(x, ndt))
         p0 = [p1] * len(rfreq)
         for i in range(1, cfg['convolutional_layer_count'] + 1):
             k = tw['t%d/conv%d/kernel' % (t, i)]
@@ -92,6 +95,7 @@ def _forward_torch(w, cfg, xs):
                 if i % rfreq[ri] == 0:
                     a = p0[ri]
                     if a.shape != p1.shape:
+                        n_proj += 1
                         if a.shape[1] != p1.shape[1]:
                             sk = tw['t%d/sc%d/kernel' % (t, i)]
                             a = F.conv2d(a, sk.permute(3, 2, 0, 1).contiguous(), tw['t%d/sc%d/bias' % (t, i)])
@@ -106,23 +110,57 @@ def _forward_torch(w, cfg, xs):
         flats.append(p1.permute(0, 2, 3, 1).reshape(p1.shape[0], -1))      # Keras flatten: (H, W, C)
     c = torch.cat(flats, 1)
     m = torch.sigmoid(c @ tw['dense1/kernel'] + tw['dense1/bias'])
-    return (m @ tw['dense2/kernel'] + tw['dense2/bias']).numpy()
+    lg = m @ tw['dense2/kernel'] + tw['dense2/bias']
+    if cfg['output_classes'] > 1:
+        y = torch.softmax(lg, dim=1)
+    else:
+        lo, hi = cfg['output_range']
+        y = torch.sigmoid(lg) * (hi - lo) + lo
+    return lg.numpy(), y.numpy(), n_proj
 
 
-@pytest.mark.parametrize('name', ['velocity', 'pitch'])
-def test_full_forward_logits(name):
+def _head(name, n_fft):
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'amt-saga_amd'))
     from amt_saga import heads, hyperparams
-    p = hyperparams.Hyperparams(N=2048)
-    h = heads.VelocityClassifier(p) if name == 'velocity' else heads.pitch_classifier(p)
-    cfg = orc.head_config(p, name)
+    p = hyperparams.Hyperparams(N=n_fft)
+    if name == 'velocity':
+        h = heads.VelocityClassifier(p)
+    elif name == 'pitch':
+        h = heads.pitch_classifier(p)
+    elif name == 'timing':
+        h = heads.timming_classifier(p)
+    else:
+        h = heads.InstrumentClassifier(p, name)
+    return p, h, orc.head_config(p, name)
+
+
+@pytest.mark.parametrize('name,n_fft,B', [('velocity', 2048, 2), ('pitch', 2048, 2), ('instrument', 2048, 2),
+                                          ('instrument_dual', 2048, 2), ('timing', 4096, 2), ('timing', 2048, 1)])
+def test_full_forward_every_head(name, n_fft, B):
+    """Every head graph the path uses -- pitch, velocity, instrument, the two-tower instrument_dual and the
+    timing head at N = 4096 (20 x 258) and N = 2048 (20 x 516; > 97 % of the loop's flops: 4 x 16 kernels,
+    2 x 8 pools, the 1x1-conv + avg-pool shortcut projections at layers 14 and 26) -- evaluated by torch's own
+    conv / batch-norm / pooling / linear in float32 AND float64, against the numpy oracle in the same
+    precision: logits, the output activation (softmax / sigmoid + range scaling, RDCNN.py:218-221,308-310)
+    and the float64 pair to 1e-9."""
+    p, h, cfg = _head(name, n_fft)
     rng = np.random.default_rng(3)
-    xs = [(rng.random((2,) + tuple(s[:2]) + (1,)) ** 2).astype(np.float32) for s in cfg['input_shapes']]
-    got = orc.forward(h.weights, cfg, xs, np.float32, return_logits=True)
-    want = _forward_torch(h.weights, cfg, xs)
-    assert got.shape == want.shape
-    assert np.abs(got - want).max() < 1e-4 * max(np.abs(want).max(), 1.0)
+    xs = [(rng.random((B,) + tuple(s[:2]) + (1,)) ** 2).astype(np.float32) for s in cfg['input_shapes']]
+    got_lg = orc.forward(h.weights, cfg, xs, np.float32, return_logits=True)
+    got_y = orc.forward(h.weights, cfg, xs, np.float32)
+    lg32, y32, n_proj = _forward_torch(h.weights, cfg, xs, torch.float32)
+    assert got_lg.shape == lg32.shape == (B, cfg['output_classes'])
+    assert n_proj == 3 * len(xs)                                  # input -> 32, 32 -> 64 + pool, 64 -> 128 + pool
+    assert np.abs(got_lg - lg32).max() < 1e-4 * max(np.abs(lg32).max(), 1.0)
+    assert np.abs(got_y - y32).max() < 1e-4 * max(np.abs(y32).max(), 1.0)
+    got64 = orc.forward(h.weights, cfg, xs, np.float64, return_logits=True)
+    goty64 = orc.forward(h.weights, cfg, xs, np.float64)
+    lg64, y64, _ = _forward_torch(h.weights, cfg, xs, torch.float64)
+    assert np.abs(got64 - lg64).max() < 1e-9 * max(np.abs(lg64).max(), 1.0)
+    assert np.abs(goty64 - y64).max() < 1e-9 * max(np.abs(y64).max(), 1.0)
+    # and the float32 evaluations are both float32-close to the float64 truth
+    assert np.abs(got_lg - lg64).max() < 1e-4 * max(np.abs(lg64).max(), 1.0)
 
 
 def test_oracle_stft_istft_vs_scipy():
