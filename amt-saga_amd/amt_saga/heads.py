@@ -34,7 +34,7 @@ class _Head(res_net):
 
 class pitch_classifier(_Head):
     def __init__(self, params, checkpoint_prefix='checkpoint_pitch',
-                 metrics_prefix='metrics_pitch', weight_seed=101):
+                 metrics_prefix='metrics_pitch', weight_seed=101, calibrated=True):
         super().__init__(input_shapes=[(params.pitch_bands, params.pitch_frames, 1)],
                          kernel_sizes=params.kernel_size_pitch,
                          pool_sizes=params.pool_size_pitch,
@@ -49,7 +49,7 @@ class pitch_classifier(_Head):
                          checkpoint_frequency=params.checkpoint_frequency,
                          checkpoint_prefix=checkpoint_prefix,
                          metrics_prefix=metrics_prefix, metrics=[],
-                         logging_parent='AMT-SAGA', weight_seed=weight_seed)
+                         logging_parent='AMT-SAGA', weight_seed=weight_seed, calibrated=calibrated)
         self.params = params
         self._bands, self._frames = params.pitch_bands, params.pitch_frames
 
@@ -63,7 +63,7 @@ class InstrumentClassifier(_Head):
     INSTRUMENT_FOCUSED_CONST = 'instrument_focused_const'
     INSTRUMENT_DUAL = 'instrument_dual'
 
-    def __init__(self, params, variant, prefix=None, weight_seed=102):
+    def __init__(self, params, variant, prefix=None, weight_seed=102, calibrated=True):
         if variant in (InstrumentClassifier.INSTRUMENT, InstrumentClassifier.INSTRUMENT_FOCUSED,
                        InstrumentClassifier.INSTRUMENT_FOCUSED_CONST):
             input_shape = [(params.instrument_bands, params.instrument_frames, 1)]
@@ -87,7 +87,7 @@ class InstrumentClassifier(_Head):
                          checkpoint_frequency=params.checkpoint_frequency,
                          checkpoint_prefix='checkpoint_' + name,
                          metrics_prefix='metrics_' + name, metrics=[],
-                         logging_parent='AMT-SAGA', weight_seed=weight_seed)
+                         logging_parent='AMT-SAGA', weight_seed=weight_seed, calibrated=calibrated)
         self.params = params
         self.variant = variant
         self._bands, self._frames = params.instrument_bands, params.instrument_frames
@@ -98,7 +98,7 @@ class InstrumentClassifier(_Head):
 
 class VelocityClassifier(_Head):
     def __init__(self, params, checkpoint_prefix='checkpoint_velocity',
-                 metrics_prefix='metrics_velocity', weight_seed=103):
+                 metrics_prefix='metrics_velocity', weight_seed=103, calibrated=True):
         super().__init__(input_shapes=[(params.bins_velocity, params.pitch_frames, 1)],
                          kernel_sizes=params.kernel_size_velocity,
                          pool_sizes=params.pool_size_velocity,
@@ -113,7 +113,7 @@ class VelocityClassifier(_Head):
                          checkpoint_frequency=params.checkpoint_frequency,
                          checkpoint_prefix=checkpoint_prefix,
                          metrics_prefix=metrics_prefix, metrics=[],
-                         logging_parent='AMT-SAGA', weight_seed=weight_seed)
+                         logging_parent='AMT-SAGA', weight_seed=weight_seed, calibrated=calibrated)
         self.params = params
         self._bands, self._frames = params.bins_velocity, params.pitch_frames
 
@@ -123,7 +123,7 @@ class VelocityClassifier(_Head):
 
 class timming_classifier(_Head):
     def __init__(self, params, checkpoint_prefix='checkpoint_timing',
-                 metrics_prefix='metrics_timing', weight_seed=104):
+                 metrics_prefix='metrics_timing', weight_seed=104, calibrated=True):
         super().__init__(input_shapes=[(params.timing_bands, params.timing_frames, 1)],
                          kernel_sizes=params.kernel_size_timing,
                          pool_sizes=params.pool_size_timing,
@@ -138,7 +138,7 @@ class timming_classifier(_Head):
                          checkpoint_frequency=params.checkpoint_frequency,
                          checkpoint_prefix=checkpoint_prefix,
                          metrics_prefix=metrics_prefix, metrics=[],
-                         logging_parent='AMT-SAGA', weight_seed=weight_seed)
+                         logging_parent='AMT-SAGA', weight_seed=weight_seed, calibrated=calibrated)
         self.params = params
         self._bands, self._frames = params.timing_bands, params.timing_frames
 

@@ -21,6 +21,9 @@ Names follow oracle/rdcnn.py ("t0/conv1/kernel", ...); ``load_weights`` reads
 an .npz with those names.
 """
 import ctypes as C
+import hashlib
+import json
+import os
 
 import numpy as np
 import torch
@@ -31,7 +34,29 @@ from .device import empty, ptr, require_gpu, stream_ptr, to_dev
 
 # convolution arithmetic (all f32-equivalent): 2 = split-fp16 (3 f16 MFMAs per product block, default),
 # 1 = split-bf16 (6 bf16 MFMAs), 0 = f32 MFMA
-DEFAULT_MODE = int(__import__('os').environ.get('AMT_CONV_MODE', '2'))
+DEFAULT_MODE = int(os.environ.get('AMT_CONV_MODE', '2'))
+
+# BatchNorm statistics / last-Dense scaling that make the seeded synthetic heads input-sensitive
+# (tests/golden/gen_synthetic_calibration.py); keys "<topology signature>/<tensor name>"
+_CALIBRATION_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'synthetic_heads.npz')
+_calibration = None
+
+
+def topology_signature(cfg, seed):
+    """Identifies (graph, seed): the calibration table is valid for exactly that weight draw."""
+    blob = json.dumps({k: cfg[k] for k in sorted(cfg)}, sort_keys=True, default=list)
+    return '%s-s%d' % (hashlib.sha1(blob.encode()).hexdigest()[:10], int(seed))
+
+
+def _calibration_table():
+    global _calibration
+    if _calibration is None:
+        if os.path.exists(_CALIBRATION_FILE):
+            with np.load(_CALIBRATION_FILE) as z:
+                _calibration = {k: z[k] for k in z.files}
+        else:
+            _calibration = {}
+    return _calibration
 
 
 def _to_list(single):
@@ -64,7 +89,7 @@ class res_net:
                  weights_load_checkpoint_filename=None,
                  starting_checkpoint_index=1,
                  logging_parent=None,
-                 weight_seed=1234):
+                 weight_seed=1234, calibrated=True):
         self.batch_size = batch_size          # the HIP forward accepts any B
         self.out_func_min = 0
         self.out_func_max = 1
@@ -108,7 +133,7 @@ class res_net:
         if weights_load_checkpoint_filename is not None:
             self.load_weights(weights_load_checkpoint_filename)
         else:
-            self.set_weights(self.init_weights(weight_seed))
+            self.set_weights(self.init_weights(weight_seed, calibrated))
 
     # ---- topology (RDCNN.py:176-233) ---------------------------------------------
     def _walk(self):
@@ -152,11 +177,13 @@ class res_net:
         self.flat = flat
         return out
 
-    def init_weights(self, seed=1234):
-        """Synthetic weights: glorot-uniform kernels (Keras default), small random
-        biases, BN gamma~U(2.5,4.5) (large on purpose: with unit gamma a 33-layer
-        sigmoid stack forgets its input and parity tests would see nothing),
-        beta~N(0,0.2), mean~N(0,0.2), var~U(0.5,1.5)."""
+    def init_weights(self, seed=1234, calibrated=True):
+        """Synthetic weights (the reference ships none): glorot-uniform kernels (Keras default), small
+        random biases, random BN parameters.  When the calibration table holds an entry for this
+        (topology, seed) -- the heads' default seeds do -- the BN parameters and the last Dense are
+        replaced by the calibrated ones: BN moving statistics equal to the statistics of the layer's
+        own input on the loop's features, as a trained model has them, so that the head's output
+        moves with its input (tests/golden/gen_synthetic_calibration.py)."""
         rng = np.random.default_rng(seed)
         w = {}
         for name, shape in self.layout:
@@ -178,6 +205,17 @@ class res_net:
             else:
                 a = rng.uniform(0.5, 1.5, shape)
             w[name] = a.astype(np.float32)
+        self.calibrated = False
+        if calibrated:
+            tab, sig = _calibration_table(), topology_signature(self.cfg, seed) + '/'
+            for name, shape in self.layout:
+                a = tab.get(sig + name)
+                if a is not None:
+                    if tuple(a.shape) != tuple(shape):
+                        raise ValueError('Invalid Input shape. Expected: {} . Got: {} ({})'.format(
+                            shape, a.shape, name))
+                    w[name] = np.asarray(a, np.float32)
+                    self.calibrated = True
         return w
 
     def pack_weights(self, w):

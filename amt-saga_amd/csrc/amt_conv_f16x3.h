@@ -16,14 +16,17 @@
 //
 // Range.  f16 spans 2^-14 .. 65504, so operands are pre-scaled by exact powers of two:
 //   * weights: per layer, 2^sw with max|w| 2^sw in [8, 16)                         (host)
-//   * activations: per layer and launch, 2^sa with  bound * 2^sa < 2^13, where
-//     bound = alpha * X + beta is a static upper bound of the layer's input derived from
-//     the folded BN parameters (sigmoid outputs are in (0,1); residual sums and projection
-//     shortcuts are |.|-linear in the bound of their sources) and X = max|network input|
-//     measured on the device by absmax_kernel before the first layer.
-//   2^-(sa+sw) is folded into the BN scale in the epilogue (exact).  Scaled values below
+//   * activations: per layer, per launch and PER WINDOW, 2^sa with  amax * 2^sa < 2^13, where amax is
+//     the MEASURED max |input| of that window: every producer of a convolution input (absmax_kernel for
+//     the network input, the epilogues of conv1_mfma_kernel and of this kernel) leaves max |output| per
+//     window in a device array (atomicMax of non-negative float bits), which the consumer reads.  A
+//     max-pool between two layers keeps the bound valid.  Measured, not derived from the folded BN
+//     parameters: a static bound compounds over the residual blocks and, with realistic (trained-like) BN
+//     statistics, ends up orders of magnitude above the activations, wasting the f16 range; and per
+//     window, so that a window's result does not depend on the other windows of its batch.
+//   2^-(sa+sw) is applied per output row in the epilogue (exact).  Scaled values below
 //   2^-14 (f16 subnormals) are flushed to zero in both terms: an absolute error below
-//   2^-25 of the scaled bound, i.e. < 2^-38 relative to the activation bound.
+//   2^-25 of the scaled bound, i.e. < 2^-38 relative to the window's largest activation.
 //
 // conv_f16x3s_kernel (512 threads, two workgroups per CU, <= 128 VGPRs, spill-free): input tile
 // [pos][plane(2)][16 ch] f16 with an 80-B pitch = 5 x 16-B slots, split while staging; weights
@@ -67,19 +70,31 @@ __host__ __device__ __forceinline__ void amt_split_f16(float xs, unsigned short 
 }
 
 struct HxScale {
-    const float *xmax;        // device: max |network input| of this tower (may be null when alpha == 0)
-    float alpha, beta;        // input bound of this layer = alpha * X + beta
+    const float *amax_in;     // device [B]: max |input| of every window of this launch
+    float *amax_out;          // device [B] or null: max |output| per window (atomicMax, zeroed by the caller)
     int sw;                   // weights were scaled by 2^sw on the host
 };
+#define HX_MAXWIN 64                         // windows per workgroup tile (masked tiles of >= 4 positions)
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n,
+// exponent sa with amax * 2^sa < 2^13 (0 for an all-zero or non-finite window; clamped so that
+// 2^-(sa+sw) stays a normal float)
+__device__ __forceinline__ int hx_scale_exp(float amax) {
+    int e = 0;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &e);
+    else return 0;
+    return min(max(13 - e, -90), 90);
+}
+
+// max |x| per window: grid (blocks, B); out[b] must be zero before
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, size_t stride,
                                                       float *__restrict__ out) {
     __shared__ float red[16];
+    const float *xb = x + (size_t)blockIdx.y * stride;
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        m = fmaxf(m, fabsf(x[i]));                       // fmaxf drops NaNs
+        m = fmaxf(m, fabsf(xb[i]));                      // fmaxf drops NaNs
     m = block_max(m, red);
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(out) + blockIdx.y, __float_as_int(m));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -119,7 +134,10 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [2][GV4]
     int *pos_sp = reinterpret_cast<int *>(wbuf + 2 * GV4);          // [PCAP]
     int *pos_win = pos_sp + PCAP;
-    char *in_lds = reinterpret_cast<char *>(pos_win + PCAP);        // [POSIN][80 B]
+    float *pos_os = reinterpret_cast<float *>(pos_win + PCAP);      // [PCAP] 2^-(sa + sw) of the row's window
+    float *win_is = pos_os + PCAP;                                  // [HX_MAXWIN] 2^sa of the tile's windows
+    int *win_max = reinterpret_cast<int *>(win_is + HX_MAXWIN);     // [HX_MAXWIN] max |output| (float bits)
+    char *in_lds = reinterpret_cast<char *>(win_max + HX_MAXWIN);   // [POSIN][80 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,22 +156,21 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     const int r0 = tr * p.TH, c0 = tc * p.TW;
     const int ptile = p.TH * p.TW;
 
-    int sa;
-    {
-        float bnd = hs.beta;
-        if (hs.alpha != 0.f) bnd += hs.alpha * hs.xmax[0];
-        int e = 0;
-        if (bnd > 0.f && bnd < 3.0e38f) (void)frexpf(bnd, &e);
-        sa = __builtin_amdgcn_readfirstlane(13 - e);
+    // per-window scales of this tile (measured max |input| of each window)
+    if (tid < HX_MAXWIN) {
+        const int gw = win0 + tid;
+        const int sa = (tid < p.NWIN && gw < p.B) ? hx_scale_exp(hs.amax_in[gw]) : 0;
+        win_is[tid] = __uint_as_float((unsigned)(127 + sa) << 23);
+        win_max[tid] = 0;
     }
-    const float in_scale = __uint_as_float((unsigned)(127 + sa) << 23);
-
     for (int q = tid; q < PCAP; q += 512) {
         const int w_ = q / ptile, rem = q - w_ * ptile;
         const int r = rem / p.TW, c = rem - r * p.TW;
         const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
         pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
         pos_win[q] = win0 + w_;
+        const int sa = ok ? hx_scale_exp(hs.amax_in[win0 + w_]) : 0;
+        pos_os[q] = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
     }
     // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
     // PAIR of taps x 16 channels: k-group g = (tap t + g%2, channels 8*(g/2) .. +7); the second tap
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             const int wr = pc / TWin, ci = pc - wr * TWin;
             const int w_ = wr / THin, ri = wr - w_ * THin;
             const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
-            sdst[u] = (wr * RP + ci) * HX_PSTRIDE + cg * 16;
+            sdst[u] = ((wr * RP + ci) * HX_PSTRIDE + cg * 16) | (w_ << 24);       // LDS offset | window slot
             if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W)
                 ssrc[u] = p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + cg * 8;
         }
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sv[u][1]) : "v"(src) : "memory");
         }
     };
-    auto split_store = [&](const float (&v)[8], int dsto) {
+    auto split_store = [&](const float (&v)[8], int dsto, float in_scale) {
         unsigned short h[2][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) amt_split_f16<false>(v[e] * in_scale, h[0][e], h[1][e]);
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = ssrc[u] ? __uint_as_float(sv[u][e >> 2][e & 3]) : 0.f;
-            split_store(v, sdst[u]);
+            split_store(v, sdst[u] & 0xFFFFFF, win_is[sdst[u] >> 24]);
         }
         }
         for (int it = (MASKED ? 0 : HXS_NIT * 512) + tid; it < items; it += 512) { // masked tiles; items beyond the prefetch slots
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 const float4 x0 = src[0], x1 = src[1];
                 v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
             }
-            split_store(v, (wr * RP + ci) * HX_PSTRIDE + cg * 16);
+            split_store(v, (wr * RP + ci) * HX_PSTRIDE + cg * 16, win_is[w_]);
         }
         if (ch == 0) {                                    // weight group 0 -> LDS, group 1 -> prefetch registers
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,22 +352,26 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     __syncthreads();
     float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
     const int c4 = (lane & 7) * 4;
-    const float out_scale = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
     float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + cout_off + c4);
     if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + cout_off + c4);
     // D of a 16x16 MFMA: lane l holds rows 4*(l/16) + e, column l%16
+    float osc[2][4];                                   // 2^-(sa + sw) of this lane's eight rows
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) osc[ms][e] = pos_os[wid * 32 + ms * 16 + 4 * (lane >> 4) + e];
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
         const int jn = cout_off + ns * 16 + (lane & 15);
-        const float s1 = p.s1[jn] * out_scale, t1 = p.t1[jn];
+        const float s1 = p.s1[jn], t1 = p.t1[jn];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = ms * 16 + 4 * (lane >> 4) + e;
                 tb[row * HX_TPITCH + ns * 16 + (lane & 15)] =
-                    sigmoidf_((hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * s1 + t1);
+                    sigmoidf_(((hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * osc[ms][e]) * s1 + t1);
             }
     }
     int spq[4], gwq[4];
@@ -380,9 +401,11 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                                  fmaf(x, w4.z, 0.f) * s4.z + t4.z, fmaf(x, w4.w, 0.f) * s4.w + t4.w);
         }
     }
+    float rmax[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
+        rmax[i] = 0.f;
         if (spq[i] < 0) continue;
         if (has_sc) {
             v.x = (v.x + scv[i].x) * s2v.x + t2v.x;
@@ -390,6 +413,26 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
             v.z = (v.z + scv[i].z) * s2v.z + t2v.z;
             v.w = (v.w + scv[i].w) * s2v.w + t2v.w;
         }
+        rmax[i] = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         *reinterpret_cast<float4 *>(p.out + (size_t)gwq[i] * p.out_win_stride + (size_t)spq[i] * p.cout_total + cout_off + c4) = v;
+    }
+    // max |output| per window for the next layer's operand scaling
+    if (hs.amax_out) {
+        if (p.NWIN == 1) {
+            float m = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+            m = wave_max(m);
+            if (lane == 0) atomicMax(win_max, __float_as_int(m));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m = rmax[i];                      // eight lanes share a row
+                m = fmaxf(m, __shfl_xor(m, 1, 64));
+                m = fmaxf(m, __shfl_xor(m, 2, 64));
+                m = fmaxf(m, __shfl_xor(m, 4, 64));
+                if ((lane & 7) == 0 && spq[i] >= 0) atomicMax(win_max + (gwq[i] - win0), __float_as_int(m));
+            }
+        }
+        __syncthreads();
+        if (tid < p.NWIN && win0 + tid < p.B) atomicMax(reinterpret_cast<int *>(hs.amax_out) + win0 + tid, win_max[tid]);
     }
 }

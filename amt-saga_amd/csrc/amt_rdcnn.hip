@@ -539,6 +539,7 @@ struct Conv1Params {
     const float *w;                              // [KH*KW][COUT]
     const float *s1, *t1, *s2, *t2;
     int B, H, W, KH, KW, COUT;
+    float *amax_out = nullptr;                   // [B] max |output| per window (atomicMax; conv1_mfma_kernel) or null
 };
 #define C1_PPT 4
 __global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, 
             pos_sp[q] = (rc >= 0 && r < p.H && c < p.W) ? r * p.W + c : -1;
         }
         __syncthreads();
+        float tmax = 0.f;                                    // max |output| of this wave's share of the tile
         for (int mt = wid; mt < nmt; mt += 4) {
             const int rc = pos_rc[mt * 32 + (lane & 31)];
             const int abase = rc >= 0 ? (rc & 0xFFFF) * RPW + (rc >> 16) + (lane >> 5) : (lane >> 5);
@@ -682,8 +684,13 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Params p, int TH, 
                     v.x = (v.x + sc.x) * s2v.x + t2v.x; v.y = (v.y + sc.y) * s2v.y + t2v.y;
                     v.z = (v.z + sc.z) * s2v.z + t2v.z; v.w = (v.w + sc.w) * s2v.w + t2v.w;
                 }
+                tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 *reinterpret_cast<float4 *>(p.out + (size_t)b * p.out_win_stride + (size_t)sp * 32 + c4) = v;
             }
+        }
+        if (p.amax_out) {                                    // one window per tile
+            tmax = wave_max(tmax);
+            if (lane == 0) atomicMax(reinterpret_cast<int *>(p.amax_out) + b, __float_as_int(tmax));
         }
     }
 }
@@ -909,7 +916,6 @@ struct ConvOp {
     bool maskedh = false;
     double effh = 0;
     int sw = 0;                // weights scaled by 2^sw
-    float alpha = 0, beta = 1; // input bound = alpha * max|network input| + beta
 };
 struct ProjOp {
     int cin, cout, H, W, ph, pw, HO, WO;
@@ -1077,10 +1083,10 @@ static void choose_tile_h(ConvOp &c) {
     const int nsteps = c.kh * c.kw / (NTh == 1 ? 2 : 1);
     const size_t wbytes = 2 * (size_t)std::min(4, nsteps) * HX_SLAB_BYTES;
     auto total = [&](size_t posbytes) {
-        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + wbytes + (size_t)pcap * 8;
+        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + wbytes + (size_t)pcap * 12 + (size_t)HX_MAXWIN * 8;
     };
     if (c.H * c.W <= 64) {
-        const int nw = pcap / (c.H * c.W);
+        const int nw = std::min(pcap / (c.H * c.W), HX_MAXWIN);
         const size_t lds = total(((size_t)nw * c.H * c.W + 1) * HX_PSTRIDE);
         if (lds <= 79 * 1024) {
             c.maskedh = true; c.THh = c.H; c.TWh = c.W; c.NWINh = nw; c.ldsh = lds;
@@ -1097,7 +1103,7 @@ static void choose_tile_h(ConvOp &c) {
         if (eff > best + 1e-9) { best = eff; c.THh = TH; c.TWh = TW; c.NWINh = NWIN; c.ldsh = lds; c.effh = eff; }
     };
     if (c.H * c.W <= pcap)
-        for (int nw = pcap / (c.H * c.W); nw >= 1; --nw) consider(c.H, c.W, nw);
+        for (int nw = std::min(pcap / (c.H * c.W), HX_MAXWIN); nw >= 1; --nw) consider(c.H, c.W, nw);
     for (int TH = 1; TH <= c.H && TH <= pcap; ++TH) {
         int TW = pcap / TH;
         if (TW > c.W) TW = c.W;
@@ -1109,7 +1115,7 @@ static void choose_tile_h(ConvOp &c) {
 }
 
 template <int KH, int KW, int CIN, bool MASKED>
-static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipStream_t st) {
+static int launch_convs_t(const ConvOp &c, ConvParams p, const float *amax_in, float *amax_out, hipStream_t st) {
     auto kern = conv_f16x3s_kernel<KH, KW, CIN, MASKED>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1121,26 +1127,26 @@ static int launch_convs_t(const ConvOp &c, ConvParams p, const float *xmax, hipS
     p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
-    HxScale hs{xmax, c.alpha, c.beta, c.sw};
+    HxScale hs{amax_in, amax_out, c.sw};
     kern<<<dim3(grid, c.nsliceh), 512, c.ldsh, st>>>(p, c.whs, hs);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 template <int KH, int KW>
-static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
+static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *amax_in, float *amax_out, hipStream_t st) {
     // every layer runs 32-wide N-slices (blockIdx.y) of the single-tile kernel; small images its masked form
     if (!c.whs || c.cwh != 32) return AMT_E_UNSUPPORTED;
 #define HXS_CASE(CI)                                                                       \
-    if (c.cin == CI) return c.maskedh ? launch_convs_t<KH, KW, CI, true>(c, p, xmax, st)   \
-                                      : launch_convs_t<KH, KW, CI, false>(c, p, xmax, st);
+    if (c.cin == CI) return c.maskedh ? launch_convs_t<KH, KW, CI, true>(c, p, amax_in, amax_out, st)   \
+                                      : launch_convs_t<KH, KW, CI, false>(c, p, amax_in, amax_out, st);
     HXS_CASE(32) HXS_CASE(64) HXS_CASE(128)
 #undef HXS_CASE
     return AMT_E_UNSUPPORTED;
 }
-static int launch_convh(const ConvOp &c, const ConvParams &p, const float *xmax, hipStream_t st) {
-    if (c.kh == 4 && c.kw == 16) return launch_convh_k<4, 16>(c, p, xmax, st);
-    if (c.kh == 4 && c.kw == 2) return launch_convh_k<4, 2>(c, p, xmax, st);
-    if (c.kh == 2 && c.kw == 2) return launch_convh_k<2, 2>(c, p, xmax, st);
+static int launch_convh(const ConvOp &c, const ConvParams &p, const float *amax_in, float *amax_out, hipStream_t st) {
+    if (c.kh == 4 && c.kw == 16) return launch_convh_k<4, 16>(c, p, amax_in, amax_out, st);
+    if (c.kh == 4 && c.kw == 2) return launch_convh_k<4, 2>(c, p, amax_in, amax_out, st);
+    if (c.kh == 2 && c.kw == 2) return launch_convh_k<2, 2>(c, p, amax_in, amax_out, st);
     return AMT_E_UNSUPPORTED;
 }
 
@@ -1254,14 +1260,11 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
         tw.in_h = d.in_h[t]; tw.in_w = d.in_w[t]; tw.ph = d.pool_h[t]; tw.pw = d.pool_w[t];
         int H = tw.in_h, W = tw.in_w, C = 1, fo = 32;
         int p0H = H, p0W = W, p0C = 1;
-        // |activation| <= a * X + b with X = max |tower input| (split-fp16 operand scaling)
-        double cur_a = 1, cur_b = 0, p0_a = 1, p0_b = 0;
         tw.max_act = (size_t)H * W;
         const int kh = d.kh[t], kw = d.kw[t];
         for (int i = 1; i <= d.conv_layers; ++i) {
             ConvOp c;
             c.cin = C; c.cout = fo; c.H = H; c.W = W; c.kh = kh; c.kw = kw;
-            c.alpha = (float)(cur_a * (1.0 + 1e-6)); c.beta = (float)(cur_b * (1.0 + 1e-6));
             const float *kern = take((size_t)kh * kw * C * fo);
             const float *bias = take(fo);
             BN bn{take(fo), take(fo), take(fo), take(fo)};
@@ -1341,7 +1344,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     c.cwh = 32; c.nsliceh = fo / 32;                   // 32-wide N-slices
                     choose_tile_h(c);
                     float wmax = 0.f;
-                    bool finite = std::isfinite(c.alpha) && std::isfinite(c.beta);
+                    bool finite = true;
                     for (size_t q = 0; q < (size_t)ntap * C * fo; ++q) {
                         if (!std::isfinite(kern[q])) finite = false;
                         wmax = std::max(wmax, fabsf(kern[q]));
@@ -1408,30 +1411,13 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     n->flops += 2.0 * H * W * (double)p0C * C;
                     c.sc_proj = (int)tw.projs.size();
                     tw.projs.push_back(pr);
-                    // |proj| <= max_j(|s_j| sum_c |w_cj|) * bound(p0) + max_j |t_j|  (avg-pool keeps the bound)
-                    double g = 0, tmax = 0;
-                    for (int j = 0; j < C; ++j) {
-                        double l1 = 1.0;
-                        if (pk) { l1 = 0; for (int cc = 0; cc < p0C; ++cc) l1 += fabs((double)pk[(size_t)cc * C + j]); }
-                        g = std::max(g, l1 * fabs((double)ps[j]));
-                        tmax = std::max(tmax, fabs((double)pt[j]));
-                    }
-                    p0_a = g * p0_a; p0_b = g * p0_b + tmax;
                 }
                 BN rbn{take(C), take(C), take(C), take(C)};
                 std::vector<float> rs, rt;
                 fold_bn(rbn, C, nullptr, rs, rt);
                 RD_TRY(upload(n, rs, &c.s2));
                 RD_TRY(upload(n, rt, &c.t2));
-                {   // out = (sigmoid + shortcut) * s2 + t2
-                    double smax = 0, tmax = 0;
-                    for (int j = 0; j < C; ++j) { smax = std::max(smax, fabs((double)rs[j])); tmax = std::max(tmax, fabs((double)rt[j])); }
-                    cur_a = p0_a * smax; cur_b = (1.0 + p0_b) * smax + tmax;
-                    p0_a = cur_a; p0_b = cur_b;
-                }
                 p0H = H; p0W = W; p0C = C;
-            } else {
-                cur_a = 0; cur_b = 1;                   // a sigmoid output
             }
             if (d.pool_layer_frequency > 0 && i % d.pool_layer_frequency == 0) {
                 c.pool_after = 1;
@@ -1517,8 +1503,9 @@ static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     size_t ma = 0;
     for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);
     ma = (ma + 3) & ~(size_t)3;
+    // + per-window max |activation| of the network input and of every conv layer's output (split-fp16 scaling)
     return (size_t)Bc * (4 * ma + (size_t)((n->flat + 3) & ~3) + (size_t)((n->d.dense_units + 3) & ~3) +
-                         (size_t)((n->d.output_classes + 3) & ~3)) + 8;
+                         (size_t)((n->d.output_classes + 3) & ~3) + (size_t)(n->d.conv_layers + 1)) + 8;
 }
 
 size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B) {
@@ -1551,15 +1538,15 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
         float *flatbuf = ws + (size_t)4 * Bc * ma;
         float *d1 = flatbuf + (size_t)Bc * ((flat + 3) & ~3);
         float *lg = d1 + (size_t)Bc * ((DU + 3) & ~3);
-        float *xmax = lg + (size_t)Bc * ((K + 3) & ~3);              // [n_towers] max |tower input|
+        float *amax = lg + (size_t)Bc * ((K + 3) & ~3);              // [conv_layers + 1][Bc] max |activation| per window
         int flat_off = 0;
-        if (net->mode == 2) AMT_HIP_CHECK(hipMemsetAsync(xmax, 0, 8 * sizeof(float), st));
         for (int t = 0; t < d.n_towers; ++t) {
             const Tower &tw = net->towers[t];
             const float *cur = x[t] + (size_t)b0 * tw.in_h * tw.in_w;
             if (net->mode == 2) {
-                const size_t nin = (size_t)Bc * tw.in_h * tw.in_w;
-                absmax_kernel<<<(unsigned)std::min<size_t>((nin + 1023) / 1024, 1024), 256, 0, st>>>(cur, nin, xmax + t);
+                AMT_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)(d.conv_layers + 1) * Bc * sizeof(float), st));
+                const size_t nin = (size_t)tw.in_h * tw.in_w;
+                absmax_kernel<<<dim3((unsigned)std::min<size_t>((nin + 1023) / 1024, 64), Bc), 256, 0, st>>>(cur, nin, nin, amax);
             }
             size_t cur_stride = (size_t)tw.in_h * tw.in_w;
             const float *p0 = cur; size_t p0_stride = cur_stride;
@@ -1601,10 +1588,14 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     }
                     AMT_HIP_CHECK(hipEventRecord(pe0, st));
                 }
+                // split-fp16 scaling: layer i reads amax[i] (its input) and leaves amax[i + 1] (its output)
+                float *amax_o = net->mode == 2 ? amax + (size_t)(i + 1) * Bc : nullptr;
+                bool wrote_amax = false;
                 if (c.cin == 1 && c.cout == 32 && conv_supported(c.kh, c.kw)) {
                     Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                    c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
-                                   Bc, H, W, c.kh, c.kw, c.cout};
+                                   Bc, H, W, c.kh, c.kw, c.cout, amax_o};
+                    wrote_amax = true;
                     int TH1 = 1, TW1 = 1;
                     choose_tile1(H, W, &TH1, &TW1);
                     const int th = (H + TH1 - 1) / TH1, twn = (W + TW1 - 1) / TW1;
@@ -1634,9 +1625,18 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         cp.sc1 = p0; cp.sc1_win_stride = p0_stride;
                         cp.sc1_w = rank1->w; cp.sc1_s = rank1->s; cp.sc1_t = rank1->t;
                     }
-                    const int rc = (net->mode == 2 && c.whs) ? launch_convh(c, cp, xmax + t, st)
+                    const bool fp16 = net->mode == 2 && c.whs;
+                    const int rc = fp16 ? launch_convh(c, cp, amax + (size_t)i * Bc, amax_o, st)
                                    : (net->mode >= 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;
+                    wrote_amax = fp16;
+                }
+                if (amax_o && !wrote_amax && i + 1 < L) {
+                    // the producing kernel does not measure its output: one extra pass (layers the split-fp16
+                    // kernel is not built for; none of the reference's head topologies)
+                    const size_t nout = (size_t)H * W * c.cout;
+                    absmax_kernel<<<dim3((unsigned)std::min<size_t>((nout + 1023) / 1024, 64), Bc), 256, 0, st>>>(
+                        o, nout, o_stride, amax_o);
                 }
                 if (net->prof_on) {
                     AMT_HIP_CHECK(hipEventRecord(pe1, st));

@@ -58,7 +58,7 @@ def test_c1_hip_vs_oracle(golden_dir):
     C = ac.slice_C(0.5, 1.0, p.pitch_frames, bins_per_tone=p.pitch_bins_per_tone)
     assert C.shape == (174, 8)
     assert np.abs(C - C_ref).max() / C_ref.max() < 1e-4
-    for mode in (0, 1):
+    for mode in (0, 1, 2):                             # f32 MFMA, split-bf16, split-fp16 (the default)
         head.set_mode(mode)
         y = head.classify(C / C.max())
         assert y.shape == (1, 1)

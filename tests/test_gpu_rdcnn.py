@@ -1,11 +1,30 @@
 """GPU parity: HIP RDCNN forward (fp32 MFMA implicit GEMM) and CQT slices vs the
 numpy oracle on shared synthetic weights / seeded inputs."""
+import json
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 REL = 1e-4
+RATIOS = []          # (head, mode, e_gpu, e_cpu): distance of the GPU / CPU float32 results from the float64 oracle
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _dump_ratios():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'rdcnn_error_vs_f64.json'), 'w') as f:
+            json.dump(RATIOS, f, indent=1)
+    except OSError:
+        pass
+    for r in RATIOS:
+        print('e_gpu/e_cpu  %-34s mode %d  gpu %.3g  cpu %.3g  ratio %.2f' %
+              (r['head'], r['mode'], r['e_gpu'], r['e_cpu'], r['e_gpu'] / max(r['e_cpu'], 1e-30)))
 
 
 @pytest.fixture(scope='module')
@@ -24,18 +43,19 @@ def _inputs(shape, B, seed):
     return (rng.random((B,) + tuple(shape)) ** 2).astype(np.float32)
 
 
-def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1, 2)):
+def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1, 2), name=None, xs=None):
     """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16) against the oracle."""
     out = None
     for mode in modes:
         head.set_mode(mode)
-        out = _check_head_mode(env, head, cfg, B, seed, near_tie)
+        out = _check_head_mode(env, head, cfg, B, seed, near_tie, name or type(head).__name__, mode, xs)
     head.set_mode(0)
     return out
 
 
-def _check_head_mode(env, head, cfg, B, seed, near_tie):
-    xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
+def _check_head_mode(env, head, cfg, B, seed, near_tie, name, mode, xs=None):
+    if xs is None:
+        xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
     dev = [env['torch'].from_numpy(x).cuda() for x in xs]
     y, lg = head.predict_device(dev, return_logits=True)
     y, lg = y.cpu().numpy(), lg.cpu().numpy()
@@ -46,10 +66,14 @@ def _check_head_mode(env, head, cfg, B, seed, near_tie):
     scale = max(np.abs(ref_lg).max(), 1.0)
     assert np.abs(lg - ref_lg).max() / scale < REL, np.abs(lg - ref_lg).max()
     assert np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30) < REL
-    # the fp32 GPU result is as close to the fp64 truth as the fp32 CPU result is (x4 slack)
-    e_gpu = np.abs(y - ref64).max()
-    e_cpu = np.abs(ref - ref64).max()
-    assert e_gpu <= 4 * e_cpu + 1e-5 * max(np.abs(ref64).max(), 1.0)
+    # the GPU result is as close to the float64 truth as the float32 CPU result is: measured on the logits
+    # (the quantity every arithmetic mode produces), recorded per head and mode, and bounded at twice the
+    # CPU's own distance plus two float32 ulps of the logit scale
+    ref_lg64 = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float64, return_logits=True)
+    e_gpu = float(np.abs(lg - ref_lg64).max())
+    e_cpu = float(np.abs(ref_lg - ref_lg64).max())
+    RATIOS.append(dict(head=name, mode=mode, e_gpu=e_gpu, e_cpu=e_cpu, logit_scale=float(scale)))
+    assert e_gpu <= 2 * e_cpu + 2.4e-7 * scale, (name, mode, e_gpu, e_cpu)
     # predicted integer indices: bit-exact away from rounding ties (SURVEY 7 hard part 4)
     if cfg['output_classes'] == 1:
         frac = np.abs(ref64 - np.floor(ref64) - 0.5)
@@ -69,23 +93,23 @@ def test_velocity_head(env):
     h = env['heads'].VelocityClassifier(p)
     cfg = env['orc'].head_config(p, 'velocity')
     assert cfg['convolutional_layer_count'] == 11
-    _check_head(env, h, cfg, 5, 1)
+    _check_head(env, h, cfg, 5, 1, name='velocity')
 
 
 def test_pitch_head(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].pitch_classifier(p)
     cfg = env['orc'].head_config(p, 'pitch')
-    y = _check_head(env, h, cfg, 3, 2)
+    y = _check_head(env, h, cfg, 3, 2, name='pitch')
     assert y.shape == (3, 1) and np.all((y >= 21) & (y <= 108))
 
 
 def test_instrument_head_and_dual(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].InstrumentClassifier(p, 'instrument')
-    _check_head(env, h, env['orc'].head_config(p, 'instrument'), 2, 3)
+    _check_head(env, h, env['orc'].head_config(p, 'instrument'), 2, 3, name='instrument')
     hd = env['heads'].InstrumentClassifier(p, 'instrument_dual')
-    _check_head(env, hd, env['orc'].head_config(p, 'instrument_dual'), 2, 4)
+    _check_head(env, hd, env['orc'].head_config(p, 'instrument_dual'), 2, 4, name='instrument_dual')
     with pytest.raises(ValueError):
         env['heads'].InstrumentClassifier(p, 'nope')
 
@@ -96,7 +120,7 @@ def test_timing_head_n4096(env):
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
     assert cfg['input_shapes'][0] == (20, 258, 1)
-    _check_head(env, h, cfg, 2, 5)
+    _check_head(env, h, cfg, 2, 5, name='timing N=4096')
 
 
 def test_timing_head_n2048_batch_independent(env):
@@ -106,7 +130,7 @@ def test_timing_head_n2048_batch_independent(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
-    _check_head(env, h, cfg, 1, 6)
+    _check_head(env, h, cfg, 1, 6, name='timing N=2048')
     torch = env['torch']
     x = torch.from_numpy(_inputs((20, 516), 13, 7)).cuda()
     y = h.predict_device([x]).cpu().numpy()
@@ -185,6 +209,61 @@ def test_split_fp16_operand_range(env):
     assert float((l2 - l0).abs().max()) / max(float(l0.abs().max()), 1.0) < 2e-5
 
 
+def test_chunk_boundary_520_windows(env):
+    """A 520-window batch crosses the 512-window chunk of amt_rdcnn_forward (second chunk: 8 windows, the
+    workspace is reused): every window's logits are bit-identical to a small batch of the same windows, in
+    all three arithmetics, and an oracle subset straddling the boundary agrees."""
+    torch = env['torch']
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].pitch_classifier(p)
+    cfg = env['orc'].head_config(p, 'pitch')
+    x = _inputs((174, 8), 520, 23)
+    xd = torch.from_numpy(x).cuda()
+    pick = [0, 255, 509, 510, 511, 512, 513, 519]
+    xs = torch.from_numpy(x[pick]).cuda()
+    for mode in (0, 1, 2):
+        h.set_mode(mode)
+        y, lg = h.predict_device([xd], return_logits=True)
+        ys, lgs = h.predict_device([xs], return_logits=True)
+        assert torch.equal(lg[pick], lgs) and torch.equal(y[pick], ys), mode
+        tail, lgt = h.predict_device([xd[508:].contiguous()], return_logits=True)
+        assert torch.equal(lg[508:], lgt), mode
+    sub = [509, 511, 512, 519]
+    ref = env['orc'].forward(h.weights, cfg, [x[sub][..., None]], np.float32, return_logits=True)
+    assert np.abs(lg[sub].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1.0) < REL
+    # the outputs move with the input (calibrated synthetic weights): not a constant function
+    assert len(np.unique(np.rint(y.cpu().numpy()))) >= 8
+    h.set_mode(0)
+
+
+def test_mixed_scale_chunk_mode2(env):
+    """Split-fp16 operand scaling is per window (measured max |activation| of that window, every layer):
+    one window a million times louder, one a million times quieter and an all-zero one inside a chunk leave
+    the other windows' results bit-identical, and each of them still matches the f32-MFMA result."""
+    torch = env['torch']
+    p = env['hp'].Hyperparams(N=2048)
+    for h, shape in ((env['heads'].VelocityClassifier(p), (36, 8)), (env['heads'].pitch_classifier(p), (174, 8))):
+        x = _inputs(shape, 9, 31)
+        xm = x.copy()
+        xm[2] *= np.float32(1e6)
+        xm[5] *= np.float32(1e-6)
+        xm[7] = 0
+        h.set_mode(2)
+        l_plain = h.predict_device([torch.from_numpy(x).cuda()], return_logits=True)[1]
+        l_mixed = h.predict_device([torch.from_numpy(xm).cuda()], return_logits=True)[1]
+        keep = [0, 1, 3, 4, 6, 8]
+        assert torch.equal(l_plain[keep], l_mixed[keep])
+        assert bool(torch.isfinite(l_mixed).all())
+        h.set_mode(0)
+        l_ref = h.predict_device([torch.from_numpy(xm).cuda()], return_logits=True)[1]
+        assert float((l_mixed - l_ref).abs().max()) / max(float(l_ref.abs().max()), 1.0) < 2e-5
+        # a window alone gives the same bits as inside the batch
+        h.set_mode(2)
+        alone = h.predict_device([torch.from_numpy(xm[2:3]).cuda()], return_logits=True)[1]
+        assert torch.equal(alone, l_mixed[2:3])
+        h.set_mode(0)
+
+
 def test_classify_contract(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].VelocityClassifier(p)
@@ -254,4 +333,4 @@ def test_small_topologies(env, case):
                                feature_expand_frequency=case['ef'],
                                pool_layer_frequency=case['pf'],
                                residual_layer_frequencies=case['r'], weight_seed=77)
-    _check_head(env, net, net.cfg, 6, 11)
+    _check_head(env, net, net.cfg, 6, 11, name='shallow %s k%s' % (case['shape'], case['k']))

