@@ -65,6 +65,12 @@ PROTOTYPES = {
                                      C.c_int, vp, vp, vp, C.c_int, vp]),
     'amt_short_window': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                    vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'amt_gather_frames': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_size_t, vp]),
+    'amt_amplitude_to_db': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_float,
+                                      C.c_float, vp, vp]),
+    'amt_db_to_amplitude': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
+    'amt_spectral_flatness': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float, vp, vp]),
     'amt_cqt_slices': (C.c_int, [C.POINTER(CqtArgs), vp]),
     'amt_round_clamp': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'amt_argmax_rows': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),

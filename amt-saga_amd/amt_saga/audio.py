@@ -207,6 +207,52 @@ class AudioBatch:
         return out
 
 
+def gather_frames(src, index, F, elem=1, band_min=0, bands=None):
+    """Frame / band selection on the device (amt_gather_frames).  src: device [T, ldf] (elem 1) or
+    [T, ldf, 2] (elem 2), or batched with a leading B; index: int sequence or device int32 tensor of
+    source frames (-1 = zero frame), one table for all windows.  Returns [n, ldf_out(, 2)] (or batched),
+    ldf_out = `bands` rounded up to 4; bins outside [0, F) and frames outside [0, T) read as zero."""
+    lib = _lib.load()
+    batched = src.dim() == (3 if elem == 1 else 4)
+    s = src if batched else src[None]
+    B, T, ldf = s.shape[0], s.shape[1], s.shape[2]
+    bands = F if bands is None else int(bands)
+    ldo = (bands + 3) & ~3
+    idx = index if isinstance(index, torch.Tensor) else to_dev(np.asarray(index, dtype=np.int32), torch.int32)
+    n = int(idx.shape[-1])
+    shape = (B, n, ldo) if elem == 1 else (B, n, ldo, 2)
+    out = empty(shape)
+    if n:
+        if T == 0:
+            out.zero_()
+        else:
+            _lib.check(lib.amt_gather_frames(ptr(s), B, T, int(F), ldf, T * ldf * elem, elem, ptr(idx), 0, n,
+                                             int(band_min), bands, ptr(out), ldo, n * ldo * elem, stream_ptr()))
+    return out if batched else out[0]
+
+
+def amplitude_to_db(mag, ref, F, window_max=None, amin=1e-5, top_db=80.0):
+    """librosa.amplitude_to_db on the device for [B, T, ldf] magnitudes; ref / window_max: [B] tensors."""
+    lib = _lib.load()
+    B, T, ldf = mag.shape
+    if window_max is None:
+        window_max = empty((B,))
+        _lib.check(lib.amt_window_max(ptr(mag), B, T, ldf, T * ldf, ptr(window_max), stream_ptr()))
+    out = empty((B, T, ldf))
+    _lib.check(lib.amt_amplitude_to_db(ptr(mag), B, T, int(F), ldf, T * ldf, ptr(ref), ptr(window_max),
+                                       float(amin), -1.0 if top_db is None else float(top_db), ptr(out),
+                                       stream_ptr()))
+    return out
+
+
+def db_to_amplitude(db, ref, F):
+    lib = _lib.load()
+    B, T, ldf = db.shape
+    out = empty((B, T, ldf))
+    _lib.check(lib.amt_db_to_amplitude(ptr(db), B, T, int(F), ldf, T * ldf, ptr(ref), ptr(out), stream_ptr()))
+    return out
+
+
 def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     """slice_C for a batch (util_audio.py:411-434, build-defined CQT):
     wave [B, L] f32 device; src_frame [B, frames] int32; table = (phase_inc uint32
@@ -284,25 +330,34 @@ def _from_tm(t, Fb, complex_=False):
     return np.ascontiguousarray(h[:, :Fb].T)
 
 
+SPECTRAL = ('mag', 'ph', 'D')          # attributes with a device copy; elem floats per bin: 1, 2, 1
+_ELEM = {'mag': 1, 'ph': 2, 'D': 1}
+
+
 class audio_complete:
-    """Same constructor, properties and methods as util_audio.audio_complete."""
+    """Same constructor, properties and methods as util_audio.audio_complete (util_audio.py:32-527).
+
+    Every spectral attribute (mag, ph, D) has two faces: a device tensor in the frame-major layout
+    (``_d[name]``: [T, ldf] or [T, ldf, 2]), which all numeric work reads and writes, and a host
+    array in the reference's [F, T] layout (``_h[name]``), materialised only when the caller looks
+    at it or hands one in.  Window management (section / slice / concat / resize / section_power) is
+    expressed as frame index maps executed by amt_gather_frames -- a column range of the
+    reference's arrays is a row range here, zero padding is the index -1 -- so a window never
+    travels to the host to be cut."""
 
     def __init__(self, waveform, n_fft, hop_length=None, center=True, sample_rate=44100):
         self._wf = waveform
         self._F = None
-        self._mag = None        # host views are materialised lazily from the device tensors
+        self._h = {k: None for k in SPECTRAL}       # host views, [F, T]
+        self._d = {k: None for k in SPECTRAL}       # device tensors, frame-major
         self._ref_mag = None
-        self._ph = None
-        self._D = None
-        self._dmag = None       # device [T, ldf]
-        self._dph = None        # device [T, ldf, 2]
         self.sr = sample_rate
         self.N = n_fft
         self.center = center
         self.hl = hop_length if hop_length is not None else int(np.floor(n_fft / 4))
         self._fft_freq = fft_frequencies(sample_rate, n_fft)
 
-    # ---- helpers ----------------------------------------------------------------
+    # ---- the two faces of a spectral attribute --------------------------------------
     @property
     def _Fb(self):
         return self.N // 2 + 1
@@ -311,43 +366,60 @@ class audio_complete:
     def _ldf(self):
         return ldf_of(self.N)
 
+    def _has(self, name):
+        return self._h[name] is not None or self._d[name] is not None
+
+    def _dev(self, name):
+        """Device tensor of a present attribute (uploads a host-set array once)."""
+        if self._d[name] is None and self._h[name] is not None:
+            self._d[name] = _to_tm(self._h[name], self._ldf, complex_=(name == 'ph'))
+        return self._d[name]
+
+    def _host(self, name):
+        if self._h[name] is None and self._d[name] is not None:
+            self._h[name] = _from_tm(self._d[name], self._Fb, complex_=(name == 'ph'))
+        return self._h[name]
+
+    def _put(self, name, host=None, dev=None):
+        self._h[name], self._d[name] = host, dev
+
+    def _frames_of(self, name):
+        if self._d[name] is not None:
+            return int(self._d[name].shape[0])
+        return int(self._h[name].shape[1])
+
+    # the reference's private fields, for callers (and tests) that poke them directly
+    _mag = property(lambda self: self._host('mag'), lambda self, v: self._put('mag', host=v))
+    _ph = property(lambda self: self._host('ph'), lambda self, v: self._put('ph', host=v))
+    _D = property(lambda self: self._host('D'), lambda self, v: self._put('D', host=v))
+
     def _batch(self):
-        b = AudioBatch(None, self.N, self.hl, self.center, self.sr)
-        return b
+        return AudioBatch(None, self.N, self.hl, self.center, self.sr)
+
+    def _scalar(self, v):
+        return to_dev(np.array([v], dtype=np.float32))
 
     def _run_stft(self):
         wf = np.asarray(self.wf, dtype=np.float32)
         b = AudioBatch(wf[None, :], self.N, self.hl, self.center, self.sr).stft(True)
-        self._dmag, self._dph = b.mag[0], b.ph[0]
-        self._mag = None
-        self._ph = None
+        self._put('mag', dev=b.mag[0])
+        self._put('ph', dev=b.ph[0])
 
-    def _have_mag(self):
-        return self._mag is not None or self._dmag is not None
-
-    def _have_ph(self):
-        return self._ph is not None or self._dph is not None
-
-    def _dev_mag(self):
-        if self._dmag is None:
-            self._dmag = _to_tm(self._mag, self._ldf)
-        return self._dmag
-
-    def _dev_ph(self):
-        if self._dph is None:
-            self._dph = _to_tm(self._ph, self._ldf, True)
-        return self._dph
+    def _mag_from_db(self):
+        """mag = db_to_amplitude(D, ref_mag or 1) (util_audio.py:99-101,122-124,143-145), on the device."""
+        if self._ref_mag is None:
+            self._ref_mag = 1.0
+        m = db_to_amplitude(self._dev('D')[None], self._scalar(self._ref_mag), self._Fb)[0]
+        self._put('mag', dev=m)
 
     def clone(self):                                        # util_audio.py:69-87
         ac = audio_complete(None if self._wf is None else np.array(self._wf, copy=True),
                             sample_rate=self.sr, n_fft=self.N, center=self.center,
                             hop_length=self.hl)
-        ac._F = None if self._F is None else self._F.copy()
-        ac._mag = None if self._mag is None else self._mag.copy()
-        ac._ph = None if self._ph is None else self._ph.copy()
-        ac._D = None if self._D is None else np.array(self._D, copy=True)
-        ac._dmag = None if self._dmag is None else self._dmag.clone()
-        ac._dph = None if self._dph is None else self._dph.clone()
+        ac._F = None if self._F is None else np.array(self._F, copy=True)
+        for k in SPECTRAL:
+            ac._put(k, None if self._h[k] is None else np.array(self._h[k], copy=True),
+                    None if self._d[k] is None else self._d[k].clone())
         ac._ref_mag = self._ref_mag
         return ac
 
@@ -357,32 +429,25 @@ class audio_complete:
         if self._wf is None:
             if self._F is not None:
                 self._wf = self._istft_complex(self._F)
-            elif self._have_mag() and self._have_ph():
+            elif self._has('mag') and self._has('ph'):
                 self._wf = self._istft_magph()
-            elif self._D is not None and self._have_ph():
-                if self._ref_mag is None:
-                    self._ref_mag = 1.0
-                self.__set_mag_host(_db_to_amplitude(self._D, self._ref_mag))
+            elif self._has('D') and self._has('ph'):
+                self._mag_from_db()
                 self._wf = self._istft_magph()
         return self._wf
 
     @wf.setter
     def wf(self, value):                                    # util_audio.py:107-114
-        self._D = None
+        for k in SPECTRAL:
+            self._put(k)
         self._ref_mag = None
-        self._mag = self._dmag = None
-        self._ph = self._dph = None
         self._F = None
         self._wf = value
 
-    def __set_mag_host(self, m):
-        self._mag = np.asarray(m)
-        self._dmag = None
-
     def _istft_magph(self):
         b = self._batch()
-        b.mag = self._dev_mag()[None]
-        b.ph = self._dev_ph()[None]
+        b.mag = self._dev('mag')[None]
+        b.ph = self._dev('ph')[None]
         return b.istft()[0].cpu().numpy()
 
     def _istft_complex(self, Fc):
@@ -394,129 +459,109 @@ class audio_complete:
     @property
     def F(self):                                            # util_audio.py:116-129
         if self._F is None:
-            if self._have_mag() and self._have_ph():
-                self._F = self.mag * self.ph
-            elif self._D is not None and self._have_ph():
-                if self._ref_mag is None:
-                    self._ref_mag = 1.0
-                self.__set_mag_host(_db_to_amplitude(self._D, self._ref_mag))
-                self._F = self.mag * self.ph
-            elif self.wf is not None:
-                self._run_stft()
+            if not (self._has('mag') and self._has('ph')):
+                if self._has('D') and self._has('ph'):
+                    self._mag_from_db()
+                elif self.wf is not None:
+                    self._run_stft()
+            if self._has('mag') and self._has('ph'):
                 self._F = self.mag * self.ph
         return self._F
 
     @F.setter
     def F(self, value):                                     # util_audio.py:130-137
-        self._D = None
+        for k in SPECTRAL:
+            self._put(k)
         self._ref_mag = None
-        self._mag = self._dmag = None
-        self._ph = self._dph = None
         self._F = value
         self._wf = None
 
     def _magphase_of_F(self):
-        # librosa.core.magphase on a user-supplied F (util_audio.py:147): host numpy,
-        # not on the hot path (the hot path gets mag/ph straight from the STFT kernel)
+        # librosa.core.magphase of a caller-supplied F (util_audio.py:147): host numpy, off the hot path
+        # (the hot path gets mag and ph straight from the STFT kernel)
         Fc = np.asarray(self._F)
-        self._mag = np.abs(Fc)
-        self._ph = np.exp(1.j * np.angle(Fc)).astype(Fc.dtype if np.iscomplexobj(Fc) else np.complex64)
-        self._dmag = self._dph = None
+        self._put('mag', host=np.abs(Fc))
+        self._put('ph', host=np.exp(1.j * np.angle(Fc)).astype(Fc.dtype if np.iscomplexobj(Fc) else np.complex64))
 
     @property
     def mag(self):                                          # util_audio.py:139-148
-        if not self._have_mag():
-            if self._D is not None and self._have_ph():
-                if self._ref_mag is None:
-                    self._ref_mag = 1.0
-                self.__set_mag_host(_db_to_amplitude(self._D, self._ref_mag))
+        if not self._has('mag'):
+            if self._has('D') and self._has('ph'):
+                self._mag_from_db()
             elif self._F is not None:
                 self._magphase_of_F()
             else:
                 self._run_stft()
-        if self._mag is None:
-            self._mag = _from_tm(self._dmag, self._Fb)
-        return self._mag
+        return self._host('mag')
 
     @mag.setter
     def mag(self, val):                                     # util_audio.py:149-157
-        self._D = None
+        self._put('D')
         self._ref_mag = None
-        self._mag = val
-        self._dmag = None
-        if self._have_ph() and self.ph.shape != val.shape:
-            self._ph = self._dph = None
+        self._put('mag', host=val)
+        if self._has('ph') and self.ph.shape != val.shape:
+            self._put('ph')
         self._F = None
         self._wf = None
 
     @property
     def ph(self):                                           # util_audio.py:159-163
-        if not self._have_ph():
+        if not self._has('ph'):
             if self._F is not None:
                 self._magphase_of_F()
             else:
                 self._run_stft()
-        if self._ph is None:
-            self._ph = _from_tm(self._dph, self._Fb, True)
-        return self._ph
+        return self._host('ph')
 
     @ph.setter
     def ph(self, val):                                      # util_audio.py:164-168
-        self._ph = val
-        self._dph = None
+        self._put('ph', host=val)
         self._F = None
         self._wf = None
 
     @property
     def ref_mag(self):                                      # util_audio.py:170-174
         if self._ref_mag is None:
-            if not self._have_mag():
-                self.mag
+            self.mag
             b = self._batch()
-            b.mag = self._dev_mag()[None]
+            b.mag = self._dev('mag')[None]
             self._ref_mag = np.float32(b.window_max()[0].item())
         return self._ref_mag
 
     @property
     def D(self):                                            # util_audio.py:176-180
-        if self._D is None:
-            self._D = _amplitude_to_db(self.mag, self.ref_mag)
-        return self._D
+        if not self._has('D'):
+            self.mag
+            m = self._dev('mag')[None]
+            d = amplitude_to_db(m, self._scalar(self.ref_mag), self._Fb)      # max(D) from the window's own maximum
+            self._put('D', dev=d[0])
+        return self._host('D')
 
     @D.setter
     def D(self, val):                                       # util_audio.py:181-190
-        self._D = val
-        if self._have_ph() and self.ph.shape != val.shape:
-            self._ph = self._dph = None
-        self._mag = self._dmag = None
+        self._put('D', host=val)
+        if self._has('ph') and self.ph.shape != np.shape(val):
+            self._put('ph')
+        self._put('mag')
         self._F = None
         self._wf = None
 
     def _P(self, name):                                     # util_audio.py:192-207
         if name == 'wf':
             return self._wf
-        elif name == 'F':
+        if name == 'F':
             return self._F
-        elif name == 'mag':
-            return self.mag if self._have_mag() else None
-        elif name == 'ph':
-            return self.ph if self._have_ph() else None
-        elif name == 'D':
-            return self._D
+        if name in SPECTRAL:
+            return self._host(name)
         raise ValueError('Requested attribute does not exist')
 
     @property
     def shape(self):                                        # util_audio.py:209-218
-        if self._mag is not None:
-            return self._mag.shape
-        if self._dmag is not None:
-            return (self._Fb, self._dmag.shape[0])
-        if self._ph is not None:
-            return self._ph.shape
-        if self._dph is not None:
-            return (self._Fb, self._dph.shape[0])
-        if self._D is not None:
-            return self._D.shape
+        for k in SPECTRAL:
+            if self._h[k] is not None:
+                return tuple(self._h[k].shape)
+            if self._d[k] is not None:
+                return (self._Fb, int(self._d[k].shape[0]))
         return self.F.shape
 
     def _wf_len(self):
@@ -533,7 +578,7 @@ class audio_complete:
         """util_audio.py:221-259, executed by amt_subtract."""
         if isinstance(subtrahend, audio_complete):
             subtrahend.mag
-            gmag = subtrahend._dev_mag()
+            gmag = subtrahend._dev('mag')
             gmax = subtrahend.ref_mag if normalize else None
         else:
             g = np.asarray(subtrahend)
@@ -546,15 +591,14 @@ class audio_complete:
             # the reference fails here with a negative np.zeros dimension (:250-257)
             raise ValueError('negative dimensions are not allowed')
         b = self._batch()
-        b.mag = self._dev_mag()[None]
-        b.ref_max = to_dev(np.array([self.ref_mag if normalize else 0.0], dtype=np.float32))
-        gm = to_dev(np.array([gmax if normalize else 1.0], dtype=np.float32))
+        b.mag = self._dev('mag')[None]                   # in place, as the reference's `self.mag -= ...`
+        b.ref_max = self._scalar(self.ref_mag if normalize else 0.0)
+        gm = self._scalar(gmax if normalize else 1.0)
         offs = to_dev(np.array([off], dtype=np.int32), torch.int32)
         b.subtract(gmag[None], gm, None, None, offs, normalize, relu, overkill_factor)
         # mag setter semantics (:149-157): dependants cleared, phase kept (same shape)
-        self._D = None
-        self._mag = None
-        self._dmag = b.mag[0]
+        self._put('D')
+        self._put('mag', dev=b.mag[0])
         self._F = None
         self._wf = None
         self._ref_mag = None             # re-evaluated lazily, as np.max(self.mag) is in the reference
@@ -566,82 +610,96 @@ class audio_complete:
         return frames / self.shape[1] / self.sr * self._wf_len()
 
     def midi_tone_to_FFT(self, tone):                       # util_audio.py:278-284
-        f = midi_to_hz(tone)
-        ind = bisect.bisect_right(self._fft_freq, f) - 1
-        ind = 0 if ind == 0 else ind - 1
-        return ind
+        """Two bins below the first FFT bin above the tone, not below bin 0."""
+        return max(bisect.bisect_right(self._fft_freq, midi_to_hz(tone)) - 2, 0)
 
-    # ---- window management -----------------------------------------------------
+    # ---- window management: frame index maps on the device -------------------------------
+    def _take(self, index, names=SPECTRAL, with_F=True):
+        """{attribute: selected frames} for every present attribute.  index[j] = source frame of
+        output frame j, -1 = a frame of zeros.  Device attributes go through amt_gather_frames."""
+        index = np.asarray(index, dtype=np.int32)
+        out = {}
+        for k in names:
+            if self._has(k):
+                out[k] = gather_frames(self._dev(k), index, self._Fb, _ELEM[k])
+        if with_F and self._F is not None:
+            Fc = np.asarray(self._F)
+            sel = np.where(index[None, :] >= 0, Fc[:, np.clip(index, 0, max(Fc.shape[1] - 1, 0))], 0) \
+                if Fc.shape[1] else np.zeros((Fc.shape[0], len(index)), Fc.dtype)
+            out['F'] = sel
+        return out
+
+    def _wave_span(self, first, last):
+        return (int(np.floor(self._frames_to_seconds(first) * self.sr)),
+                int(np.floor(self._frames_to_seconds(last) * self.sr)))
+
     def section(self, start, end, duration_in_frames=None):  # util_audio.py:286-328
-        tfs = self._seconds_to_frames(start)
-        if duration_in_frames is None:
-            tfe = self._seconds_to_frames(end)
-        else:
-            tfe = tfs + duration_in_frames
+        """A copy of [start, end) seconds (or `duration_in_frames` frames from start); frames past the
+        end of the spectra are zeros."""
+        first = self._seconds_to_frames(start)
+        last = self._seconds_to_frames(end) if duration_in_frames is None else first + duration_in_frames
+        wave = None
         if self._wf is not None:
-            wav_start = int(np.floor(self._frames_to_seconds(tfs) * self.sr))
-            wav_end = int(np.floor(self._frames_to_seconds(tfe) * self.sr))
-            wav_cp = np.array(self._wf[wav_start:wav_end], copy=True)
-            if wav_cp.shape[0] < wav_end - wav_start:
-                wav_cp = np.concatenate((wav_cp, np.zeros(wav_end - wav_cp.shape[0])))
-        else:
-            wav_cp = None
-        nac = audio_complete(wav_cp, self.N, hop_length=self.hl, center=self.center,
-                             sample_rate=self.sr)
-
-        def cc(f):
-            if f is not None:
-                cpd = np.array(f[:, tfs:tfe], copy=True)
-                if f.shape[1] >= tfe:
-                    return cpd
-                return np.concatenate((cpd, np.zeros((f.shape[0], tfe - f.shape[1]))), axis=1)
-
-        nac._F = cc(self._F)
-        nac._ref_mag = self._ref_mag
-        nac._mag = cc(self.mag if self._have_mag() else None)
-        nac._ph = cc(self.ph if self._have_ph() else None)
-        nac._D = cc(self._D)
-        return nac
+            a, b = self._wave_span(first, last)
+            wave = np.array(self._wf[a:b], copy=True)
+            if len(wave) < b - a:                           # the reference pads by (b - len), not (b - a - len)
+                wave = np.concatenate((wave, np.zeros(b - len(wave))))
+        cut = audio_complete(wave, self.N, hop_length=self.hl, center=self.center, sample_rate=self.sr)
+        cut._ref_mag = self._ref_mag
+        if any(self._has(k) for k in SPECTRAL) or self._F is not None:
+            T = self.shape[1]
+            # columns first:last that exist, then one zero frame for every frame `last` lies past the end
+            index = list(range(T))[first:last] + [-1] * max(last - T, 0)
+            for k, v in self._take(index).items():
+                if k == 'F':
+                    cut._F = v
+                else:
+                    cut._put(k, dev=v)
+        return cut
 
     def section_power(self, name, band_min, band_max):      # util_audio.py:334-349
-        P = self._P(name)
-        h = P.shape[0]
-        cpd = np.array(P[band_min:band_max, :], copy=True)
-        if band_max > h:
-            cpd = np.concatenate((cpd, np.zeros((band_max - h, P.shape[1]))), axis=0)
-        return cpd
+        """Rows [band_min, band_max) of an attribute, zero rows past the last bin: [bands, T]."""
+        if name in SPECTRAL and self._has(name):
+            T = self._frames_of(name)
+            g = gather_frames(self._dev(name), np.arange(T), self._Fb, _ELEM[name], band_min, band_max - band_min)
+            return _from_tm(g, band_max - band_min, complex_=(name == 'ph'))
+        P = self._P(name)                                   # 'F' / 'wf' (host arrays), or an absent attribute
+        rows = np.zeros((band_max - band_min,) + P.shape[1:], dtype=P.dtype)
+        got = P[band_min:band_max]
+        rows[:got.shape[0]] = got
+        return rows
 
     def slice(self, start_in_frames, end_in_frames):        # util_audio.py:351-365
+        """Keep frames [start, end) in place.  A frame range of the frame-major device tensors is a
+        contiguous row range: a view, nothing is copied."""
+        keep = slice(start_in_frames, end_in_frames)
         if self._wf is not None:
             self._wf = self._wf[int(self._frames_to_seconds(start_in_frames) * self.sr):
                                 int(self._frames_to_seconds(end_in_frames) * self.sr)]
         if self._F is not None:
-            self._F = self._F[:, start_in_frames:end_in_frames]
-        if self._have_mag():
-            self._mag = self.mag[:, start_in_frames:end_in_frames]
-            self._dmag = None
-        if self._have_ph():
-            self._ph = self.ph[:, start_in_frames:end_in_frames]
-            self._dph = None
-        if self._D is not None:
-            self._D = self._D[:, start_in_frames:end_in_frames]
-
-    @staticmethod
-    def _concus(dest, src, axis=1):                         # util_audio.py:368-372
-        if src is None or dest is None:
-            return None
-        return np.concatenate((dest, src), axis=axis)
+            self._F = self._F[:, keep]
+        for k in SPECTRAL:
+            if self._d[k] is not None:
+                self._put(k, None if self._h[k] is None else self._h[k][:, keep], self._d[k][keep])
+            elif self._h[k] is not None:
+                self._put(k, host=self._h[k][:, keep])
 
     def concat(self, ac):                                   # util_audio.py:374-382
-        self._wf = self._concus(self._wf, ac._wf, axis=0)
-        self._F = self._concus(self._F, ac._F)
-        m = self._concus(self.mag if self._have_mag() else None,
-                         ac.mag if ac._have_mag() else None)
-        p = self._concus(self.ph if self._have_ph() else None,
-                         ac.ph if ac._have_ph() else None)
-        self._mag, self._dmag = m, None
-        self._ph, self._dph = p, None
-        self._D = self._concus(self._D, ac._D)
+        """Append another window; an attribute only one side has is dropped (None)."""
+        both = lambda a, b: a is not None and b is not None
+        self._wf = np.concatenate((self._wf, ac._wf), axis=0) if both(self._wf, ac._wf) else None
+        self._F = np.concatenate((self._F, ac._F), axis=1) if both(self._F, ac._F) else None
+        for k in SPECTRAL:
+            if self._has(k) and ac._has(k):
+                a, b = self._dev(k), ac._dev(k)
+                joined = empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]))
+                for part, at in ((a, 0), (b, a.shape[0])):
+                    if part.shape[0]:
+                        joined[at:at + part.shape[0]] = gather_frames(part, np.arange(part.shape[0]),
+                                                                      self._Fb, _ELEM[k])
+                self._put(k, dev=joined)
+            else:
+                self._put(k)
 
     @staticmethod
     def _resize(P, target_frame_count):                     # util_audio.py:384-409
@@ -666,13 +724,7 @@ class audio_complete:
         fmin = float(midi_to_hz(note_to_midi(lowest_note)))
         dev = require_gpu()
         wf = to_dev(np.asarray(self.wf, dtype=np.float32))[None]
-        t = self._seconds_to_frames(start + duration)
-        s = self._seconds_to_frames(start)
-        Ttot = self.shape[1]
-        s_c = max(0, min(s, Ttot))
-        t_c = max(s_c, min(t, Ttot))
-        rel = resize_source_frames(t_c - s_c, target_frame_count)
-        src = np.where(rel < 0, -1, rel + s_c).astype(np.int32)
+        src = self._resize_index(start, duration, target_frame_count)
         table = cqt_table(self.sr, fmin, nbins, int(12 * bins_per_tone), dev)
         out = np.zeros((nbins, target_frame_count), dtype=np.float32)
         for c0 in range(0, target_frame_count, 8):
@@ -699,29 +751,55 @@ class audio_complete:
                                           ptr(out), T, stream_ptr()))
         return out[0].cpu().numpy().astype(np.float64)
 
-    def resize(self, start, duration, target_frame_count, attribs=['F']):
-        """util_audio.py:469-507."""
-        nac = audio_complete(None, self.N, hop_length=self.hl, center=self.center,
-                             sample_rate=self.sr)
-        if self._ref_mag is not None:
-            nac._ref_mag = self._ref_mag
-        t = self._seconds_to_frames(start + duration)
-        s = self._seconds_to_frames(start)
-        for attrib in attribs:
-            if attrib == 'F':
-                nac.F = self._resize(self.F[:, s:t], target_frame_count)
-            elif attrib == 'mag':
-                nac.mag = self._resize(self.mag[:, s:t], target_frame_count)
-            elif attrib == 'ph':
-                nac.ph = self._resize(self.ph[:, s:t], target_frame_count)
-            elif attrib == 'D':
-                nac.D = self._resize(self.D[:, s:t], target_frame_count)
-            else:
-                raise ValueError('Invalid attribute requested')
-        return nac
+    def _resize_index(self, start, duration, target):
+        """Source frame of every column of _resize(X[:, s:t], target) (util_audio.py:384-409), -1 = zeros."""
+        T = self.shape[1]
+        cols = np.arange(T)[self._seconds_to_frames(start):self._seconds_to_frames(start + duration)]
+        rel = resize_source_frames(len(cols), target)
+        return np.where(rel < 0, -1, cols[np.clip(rel, 0, max(len(cols) - 1, 0))] if len(cols) else -1).astype(np.int32)
 
-    def spectral_flatness(self):
-        raise NotImplementedError('spectral_flatness is a render sanity check outside the hot path')
+    def resize(self, start, duration, target_frame_count, attribs=['F']):
+        """util_audio.py:469-507: a new object holding `target_frame_count` frames of the requested
+        attributes, cut from [start, start + duration) by the tile / crop rule of _resize."""
+        short = audio_complete(None, self.N, hop_length=self.hl, center=self.center, sample_rate=self.sr)
+        if self._ref_mag is not None:
+            short._ref_mag = self._ref_mag
+        index = None
+        for attrib in attribs:
+            if attrib not in ('F', 'mag', 'ph', 'D'):
+                raise ValueError('Invalid attribute requested')
+            getattr(self, attrib)                           # materialise it (STFT on first use)
+            if index is None:
+                index = self._resize_index(start, duration, target_frame_count)
+            if attrib == 'F':
+                short.F = self._take(index, names=())['F']
+            else:
+                got = self._take(index, names=(attrib,), with_F=False)[attrib]
+                # what the reference's setter does on assignment (:149-157, :164-168, :181-190)
+                if attrib == 'mag':
+                    short._put('D'); short._ref_mag = None
+                    if short._has('ph') and short._frames_of('ph') != target_frame_count:
+                        short._put('ph')
+                elif attrib == 'D':
+                    if short._has('ph') and short._frames_of('ph') != target_frame_count:
+                        short._put('ph')
+                    short._put('mag')
+                short._put(attrib, dev=got)
+                short._F = None
+                short._wf = None
+        return short
+
+    def spectral_flatness(self):                            # util_audio.py:330-332
+        """np.mean(librosa.feature.spectral_flatness(y=wf, n_fft, hop)) (power = 2, amin = 1e-10): per frame the
+        geometric over the arithmetic mean of max(amin, |STFT|^2).  training.py:266 skips a song whose render
+        is white noise (> 0.3)."""
+        lib = _lib.load()
+        self.mag
+        m = self._dev('mag')[None]
+        out = empty((1, m.shape[1]))
+        _lib.check(lib.amt_spectral_flatness(ptr(m), 1, m.shape[1], self._Fb, self._ldf, m.shape[1] * self._ldf,
+                                             1e-10, ptr(out), stream_ptr()))
+        return float(np.mean(out.cpu().numpy().astype(np.float64)))
 
     def save(self, filename, flac=True):
         """util_audio.py:520-527: the waveform as PCM-24 FLAC (the WAV branch is not provided)."""
@@ -729,15 +807,3 @@ class audio_complete:
             raise NotImplementedError('only FLAC output is provided')
         from . import flac as _flac
         _flac.save_float(np.asarray(self.wf), filename, sr=self.sr, bps=24)
-
-
-def _amplitude_to_db(S, ref, amin=1e-5, top_db=80.0):
-    """librosa.amplitude_to_db (plots only; util_audio.py:179)."""
-    magnitude = np.abs(np.asarray(S))
-    log_spec = 20.0 * np.log10(np.maximum(amin, magnitude))
-    log_spec -= 20.0 * np.log10(np.maximum(amin, np.abs(ref)))
-    return np.maximum(log_spec, log_spec.max() - top_db)
-
-
-def _db_to_amplitude(S_db, ref):
-    return ref * np.power(10.0, 0.05 * np.asarray(S_db))

@@ -156,21 +156,16 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     const int r0 = tr * p.TH, c0 = tc * p.TW;
     const int ptile = p.TH * p.TW;
 
-    // per-window scales of this tile (measured max |input| of each window)
-    if (tid < HX_MAXWIN) {
-        const int gw = win0 + tid;
-        const int sa = (tid < p.NWIN && gw < p.B) ? hx_scale_exp(hs.amax_in[gw]) : 0;
-        win_is[tid] = __uint_as_float((unsigned)(127 + sa) << 23);
-        win_max[tid] = 0;
-    }
+    // per-window scales of this tile: the measured max |input| of each window is requested first, so that
+    // its latency runs with the weight / tile loads issued below; the tables are written after those
+    float my_amax = 0.f;
+    if (tid < p.NWIN && win0 + tid < p.B) my_amax = hs.amax_in[win0 + tid];
     for (int q = tid; q < PCAP; q += 512) {
         const int w_ = q / ptile, rem = q - w_ * ptile;
         const int r = rem / p.TW, c = rem - r * p.TW;
         const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
         pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
         pos_win[q] = win0 + w_;
-        const int sa = ok ? hx_scale_exp(hs.amax_in[win0 + w_]) : 0;
-        pos_os[q] = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
     }
     // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
     // PAIR of taps x 16 channels: k-group g = (tap t + g%2, channels 8*(g/2) .. +7); the second tap
@@ -253,6 +248,10 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     };
     issue(0);                                             // first weight group: lands while the first tile is staged
     if constexpr (!MASKED) stage_issue(0);                 // (masked tiles are small: staged synchronously, registers saved)
+    if (tid < HX_MAXWIN) {
+        win_is[tid] = __uint_as_float((unsigned)(127 + hx_scale_exp(my_amax)) << 23);     // 2^sa
+        win_max[tid] = 0;
+    }
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
         // ---- stage + split the input tile (16 channels).  The first pass (two items per thread) was
@@ -349,6 +348,11 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         }
     }
     // ---- epilogue (see conv_f16x3_kernel) -------------------------------------------------------
+    if (tid < PCAP) {                                      // 2^-(sa + sw) of every output row's window
+        const int wl = min(max(pos_win[tid] - win0, 0), HX_MAXWIN - 1);
+        const int sa = (int)(__float_as_uint(win_is[wl]) >> 23) - 127;
+        pos_os[tid] = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
+    }
     __syncthreads();
     float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
     const int c4 = (lane & 7) * 4;

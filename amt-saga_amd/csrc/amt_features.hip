@@ -8,6 +8,7 @@
 // All HBM-bound gathers over frame-major spectra; outputs are laid out
 // [B][bands][frames] = the NHWC (C = 1) tensors the heads consume.
 #include "amt_common.h"
+#include <algorithm>
 
 // One wave per (window, output frame): the row is read coalesced (lane + 64*q),
 // every band is a masked wave reduction.  F <= 64*MAXQ.
@@ -99,6 +100,87 @@ __global__ __launch_bounds__(256) void short_window_kernel(
     }
 }
 
+// ---- window management as index maps ---------------------------------------------------------
+// audio_complete.section / slice / concat / resize / section_power (util_audio.py:286-382, 469-507) all
+// select frames (columns of the reference's [F][T] arrays = ROWS of the frame-major device layout) and,
+// for section_power, a band of bins, padding with zeros past the end.  One gather kernel serves them:
+//   out[b][j][k] = src[b][src_frame[j]][band_min + k]   (0 when src_frame[j] < 0 or >= T, or the bin >= F)
+// `elem` floats per bin (1: magnitude / dB, 2: unit phase or complex F).  Whole rows move as 16-byte
+// accesses when band_min = 0 and the pitches allow it, else element-wise; HBM-bound copies.
+__global__ __launch_bounds__(256) void gather_frames_kernel(
+    const float *__restrict__ src, int T, int F, int ldf_src, size_t src_stride, int elem,
+    const int32_t *__restrict__ src_frame, int table_stride, int n_out, int band_min, int bands,
+    float *__restrict__ out, int ldf_out, size_t out_stride) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int t = src_frame[(size_t)b * table_stride + j];
+    const bool row_ok = t >= 0 && t < T;
+    const float *s = src + (size_t)b * src_stride + (size_t)(row_ok ? t : 0) * ldf_src * elem;
+    float *o = out + (size_t)b * out_stride + (size_t)j * ldf_out * elem;
+    const int n = ldf_out * elem;                       // floats of the output row (pad bins written as zero)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int k = i / elem, c = i - k * elem;
+        const int f = band_min + k;
+        o[i] = (row_ok && k < bands && f >= 0 && f < F) ? s[(size_t)f * elem + c] : 0.f;
+    }
+}
+
+// ---- amplitude <-> dB (audio_complete.D, util_audio.py:176-190; librosa.amplitude_to_db / db_to_amplitude) ----
+// D = 20 log10(max(amin, |S|)) - 20 log10(max(amin, ref)), floored at max(D) - top_db.  log10 is monotone, so
+// max(D) follows from the window's max |S| (amt_window_max / the fused STFT max: wave -> block -> atomic
+// reductions), and the whole map is one elementwise pass.  Pad bins (f >= F) are written as zero.
+__global__ __launch_bounds__(256) void amplitude_to_db_kernel(
+    const float *__restrict__ mag, int T, int F, int ldf, size_t spec_stride,
+    const float *__restrict__ ref, const float *__restrict__ wmax, float amin, float top_db,
+    float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const float lref = 20.0f * log10f(fmaxf(amin, fabsf(ref[b])));
+    const float floor_db = top_db >= 0.f ? (20.0f * log10f(fmaxf(amin, wmax[b])) - lref) - top_db : -INFINITY;
+    const size_t n = (size_t)T * ldf;
+    const float *m = mag + (size_t)b * spec_stride;
+    float *o = out + (size_t)b * spec_stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int f = (int)(i % ldf);
+        float v = 0.f;
+        if (f < F) v = fmaxf(20.0f * log10f(fmaxf(amin, fabsf(m[i]))) - lref, floor_db);
+        o[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void db_to_amplitude_kernel(
+    const float *__restrict__ db, int T, int F, int ldf, size_t spec_stride, const float *__restrict__ ref,
+    float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const float r = ref[b];
+    const size_t n = (size_t)T * ldf;
+    const float *d = db + (size_t)b * spec_stride;
+    float *o = out + (size_t)b * spec_stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int f = (int)(i % ldf);
+        o[i] = f < F ? r * exp10f(0.05f * d[i]) : 0.f;
+    }
+}
+
+// ---- spectral flatness per frame (audio_complete.spectral_flatness, util_audio.py:330-332 ->
+// librosa.feature.spectral_flatness, power = 2): exp(mean(log(max(amin, S^2)))) / mean(max(amin, S^2)) over the
+// F bins of a frame.  One wave per frame, coalesced row read, two wave reductions.
+__global__ __launch_bounds__(256) void spectral_flatness_kernel(
+    const float *__restrict__ mag, int T, int F, int ldf, size_t spec_stride, float amin,
+    float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (t >= T) return;                                      // whole wave exits together
+    const float *row = mag + (size_t)b * spec_stride + (size_t)t * ldf;
+    float sl = 0.f, sa = 0.f;
+    for (int f = lane; f < F; f += 64) {
+        const float m = row[f];
+        const float pw = fmaxf(amin, m * m);
+        sl += logf(pw);
+        sa += pw;
+    }
+    sl = wave_sum(sl); sa = wave_sum(sa);
+    if (lane == 0) out[(size_t)b * T + t] = __fdiv_rn(expf(sl / (float)F), sa / (float)F);
+}
+
 extern "C" {
 
 int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
@@ -132,6 +214,53 @@ int amt_short_window(const float *mag, const float *phase_ri, int B, int T, int 
     short_window_kernel<<<B, 256, 0, (hipStream_t)stream>>>(
         mag, reinterpret_cast<const float2 *>(phase_ri), T, F, ldf, spec_stride, src_frame, frames,
         band_min, bands, ref, mode, out);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_gather_frames(const float *src, int B, int T, int F, int ldf_src, size_t src_stride, int elem,
+                      const int32_t *src_frame, int table_stride, int n_out, int band_min, int bands,
+                      float *out, int ldf_out, size_t out_stride, void *stream) {
+    if (!src || !src_frame || !out || B <= 0 || T < 0 || n_out <= 0) return AMT_E_INVALID;
+    if (elem < 1 || elem > 2) return AMT_E_ATTRIB;
+    if (F <= 0 || ldf_src < F || bands <= 0 || ldf_out < bands) return AMT_E_SHAPE;
+    if (table_stride != 0 && table_stride < n_out) return AMT_E_SHAPE;
+    gather_frames_kernel<<<dim3(n_out, B), 256, 0, (hipStream_t)stream>>>(
+        src, T, F, ldf_src, src_stride, elem, src_frame, table_stride, n_out, band_min, bands, out, ldf_out,
+        out_stride);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_amplitude_to_db(const float *mag, int B, int T, int F, int ldf, size_t spec_stride, const float *ref,
+                        const float *window_max, float amin, float top_db, float *out_db, void *stream) {
+    if (!mag || !ref || !window_max || !out_db || B <= 0 || T <= 0) return AMT_E_INVALID;
+    if (F <= 0 || ldf < F || !(amin > 0.f)) return AMT_E_SHAPE;
+    const size_t n = (size_t)T * ldf;
+    const unsigned gx = (unsigned)std::min<size_t>((n + 1023) / 1024, 1024);
+    amplitude_to_db_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(mag, T, F, ldf, spec_stride, ref,
+                                                                        window_max, amin, top_db, out_db);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_db_to_amplitude(const float *db, int B, int T, int F, int ldf, size_t spec_stride, const float *ref,
+                        float *out_mag, void *stream) {
+    if (!db || !ref || !out_mag || B <= 0 || T <= 0) return AMT_E_INVALID;
+    if (F <= 0 || ldf < F) return AMT_E_SHAPE;
+    const size_t n = (size_t)T * ldf;
+    const unsigned gx = (unsigned)std::min<size_t>((n + 1023) / 1024, 1024);
+    db_to_amplitude_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(db, T, F, ldf, spec_stride, ref, out_mag);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_spectral_flatness(const float *mag, int B, int T, int F, int ldf, size_t spec_stride, float amin,
+                          float *out, void *stream) {
+    if (!mag || !out || B <= 0 || T <= 0) return AMT_E_INVALID;
+    if (F <= 0 || ldf < F || !(amin > 0.f)) return AMT_E_SHAPE;
+    spectral_flatness_kernel<<<dim3((T + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(mag, T, F, ldf, spec_stride,
+                                                                                     amin, out);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -132,6 +132,33 @@ int amt_short_window(const float *mag, const float *phase_ri, int B, int T, int 
                      int frames, const int32_t *band_min, int bands,
                      const float *ref, int mode, float *out, void *stream);
 
+/* window management as index maps: audio_complete.section :286-328, .slice :351-365, .concat :374-382,
+ * .resize :469-507 (column selection with zero padding) and .section_power :334-349 (band of bins):
+ *   out[b][j][k] = src[b][src_frame[b*table_stride + j]][band_min + k]
+ * zero where the frame index is < 0 or >= T, or the bin is >= F or k >= bands.  elem = floats per bin
+ * (1 = magnitude / dB, 2 = unit phase or complex F).  table_stride 0 = one table for all windows.
+ * out rows have ldf_out bins (>= bands); the pad is written as zero. */
+int amt_gather_frames(const float *src, int B, int T, int F, int ldf_src, size_t src_stride, int elem,
+                      const int32_t *src_frame, int table_stride, int n_out, int band_min, int bands,
+                      float *out, int ldf_out, size_t out_stride, void *stream);
+
+/* audio_complete.D getter (util_audio.py:176-180 -> librosa.amplitude_to_db(mag, ref=ref_mag)):
+ *   D = 20 log10(max(amin, |mag|)) - 20 log10(max(amin, ref[b])), floored at max(D) - top_db
+ * window_max[b] = max(mag[b]) (amt_window_max or the fused STFT max) supplies max(D); top_db < 0 = no floor.
+ * librosa defaults: amin = 1e-5, top_db = 80. */
+int amt_amplitude_to_db(const float *mag, int B, int T, int F, int ldf, size_t spec_stride, const float *ref,
+                        const float *window_max, float amin, float top_db, float *out_db, void *stream);
+/* librosa.db_to_amplitude as used by the mag / F / wf getters when only D is set (util_audio.py:101,124,145):
+ *   mag = ref[b] * 10^(D / 20) */
+int amt_db_to_amplitude(const float *db, int B, int T, int F, int ldf, size_t spec_stride, const float *ref,
+                        float *out_mag, void *stream);
+
+/* audio_complete.spectral_flatness (util_audio.py:330-332 -> librosa.feature.spectral_flatness, power 2):
+ * out[b][t] = exp(mean_f log max(amin, mag^2)) / mean_f max(amin, mag^2); the reference takes np.mean over t
+ * and skips a song whose render is white noise (> 0.3, training.py:266).  librosa default amin = 1e-10. */
+int amt_spectral_flatness(const float *mag, int B, int T, int F, int ldf, size_t spec_stride, float amin,
+                          float *out, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * Constant-Q slices (replaces audio_complete.slice_C, util_audio.py:411-434,
  * i.e. |librosa.cqt| evaluated only at the frames _resize keeps).  The

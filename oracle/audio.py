@@ -111,6 +111,14 @@ def db_to_amplitude(S_db, ref=1.0):
     return ref * np.power(10.0, 0.05 * np.asarray(S_db))
 
 
+def spectral_flatness(S, amin=1e-10, power=2.0):
+    """librosa.feature.spectral_flatness(S=S): [1, T]."""
+    S_thresh = np.maximum(amin, np.asarray(S, dtype=np.float64) ** power)
+    gmean = np.exp(np.mean(np.log(S_thresh), axis=0, keepdims=True))
+    amean = np.mean(S_thresh, axis=0, keepdims=True)
+    return gmean / amean
+
+
 # ----------------------------------------------------------------------------
 # audio_complete restated  (util_audio.py:32-527)
 # ----------------------------------------------------------------------------
@@ -334,6 +342,10 @@ class AudioCompleteOracle:
         nac._ph = cc(self._ph)
         nac._D = cc(self._D)
         return nac
+
+    def spectral_flatness(self):                           # util_audio.py:330-332
+        S = np.abs(stft(self.wf, self.N, self.hl))
+        return np.mean(spectral_flatness(S))
 
     def section_power(self, name, band_min, band_max):     # util_audio.py:334-349
         P = self._P(name)

@@ -11,9 +11,11 @@ from amt_saga.hyperparams import Hyperparams
 name = sys.argv[1] if len(sys.argv) > 1 else 'timing'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 modes = [int(m) for m in (sys.argv[3] if len(sys.argv) > 3 else '0,1').split(',')]
+cal = (sys.argv[4] if len(sys.argv) > 4 else 'cal') == 'cal'      # calibrated (input-sensitive) or raw random BN statistics
 p = Hyperparams(N=2048)
 h = {'timing': heads.timming_classifier, 'pitch': heads.pitch_classifier,
-     'velocity': heads.VelocityClassifier}[name](p)
+     'velocity': heads.VelocityClassifier}[name](p, calibrated=cal)
+print('head', name, 'B', B, 'calibrated', h.calibrated)
 H, W, _ = h.cfg['input_shapes'][0]
 x = torch.rand(B, H, W, device='cuda') ** 2
 for mode in modes:

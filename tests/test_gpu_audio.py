@@ -321,3 +321,91 @@ def test_audio_complete_surface(mods):
         a._P('nope')
     with pytest.raises(ValueError):
         a.resize(0, 0.1, 8, attribs=['zzz'])
+
+
+def _mkp(audio, n_fft, mag, ph=None):
+    """Product object with injected spectra, as gen_golden_from_reference.py built the reference's."""
+    T = mag.shape[1]
+    ac = audio.audio_complete(np.zeros((n_fft // 4) * (T - 1), dtype=np.float32), n_fft)
+    ac._mag = mag.copy()
+    if ph is not None:
+        ac._ph = ph.copy()
+    return ac
+
+
+def test_window_management_vs_reference_vectors(mods, refvec):
+    """section / slice / concat / resize / section_power of the drop-in audio_complete -- frame index maps
+    executed by amt_gather_frames on the device -- against the vectors the reference's own methods emitted
+    (util_audio.py:286-382, 469-507): values bit-exact (they are copies), waveform lengths equal."""
+    audio, oa = mods
+    ac = _mkp(audio, 512, refvec['sec_mag'], refvec['sec_ph'])
+    sec = ac.section(0.2, None, 50)
+    assert sec._d['mag'] is not None and sec._h['mag'] is None          # cut on the device, never fetched
+    assert np.array_equal(sec.mag, refvec['sec_out_mag'])
+    assert np.array_equal(sec.ph, refvec['sec_out_ph'])
+    assert len(sec._wf) == int(refvec['sec_out_wf_len'])
+    sec2 = ac.section(0.1, 0.4)
+    assert np.array_equal(sec2.mag, refvec['sec2_out_mag'])
+    assert len(sec2._wf) == int(refvec['sec2_out_wf_len'])
+    ac2 = ac.clone()
+    ac2.slice(10, 40)
+    assert np.array_equal(ac2.mag, refvec['slice_out_mag'])
+    assert len(ac2._wf) == int(refvec['slice_out_wf_len'])
+    ac2.concat(sec2)
+    assert np.array_equal(ac2.mag, refvec['concat_out_mag'])
+    assert ac2.ph.shape == ac2.mag.shape
+    assert len(ac2._wf) == int(refvec['concat_out_wf_len'])
+    lo = int(refvec['secpow_lo'])
+    for i in range(4):
+        start, dur = refvec['rsz%d_args' % i]
+        rs = ac.resize(float(start), float(dur), 8, attribs=['mag', 'ph'])
+        assert np.array_equal(rs.mag, refvec['rsz%d_mag' % i])
+        assert np.array_equal(rs.ph, refvec['rsz%d_ph' % i])
+        assert np.array_equal(rs.section_power('mag', lo, lo + 348), refvec['rsz%d_secpow' % i])
+        assert np.array_equal(rs.section_power('mag', 200, 548), refvec['rsz%d_secpow_hi' % i])
+    # an attribute only one side has is dropped by concat; slicing keeps views consistent
+    a = _mkp(audio, 512, refvec['sec_mag'])
+    a.concat(sec2)
+    assert a._has('mag') and not a._has('ph')
+    with pytest.raises(ValueError):
+        ac.resize(0, 0.1, 8, attribs=['nope'])
+
+
+def test_db_and_flatness_on_device(mods):
+    """audio_complete.D (amt_amplitude_to_db: librosa.amplitude_to_db(mag, ref=ref_mag), floor at max - 80 dB),
+    its inverse through the D setter (amt_db_to_amplitude) and spectral_flatness (amt_spectral_flatness)
+    against the oracle's restatement of the librosa formulas."""
+    audio, oa = mods
+    wf = _signal(512 * 60, 5)
+    wf[512 * 30:] *= 1e-6                                    # a quiet half: exercises the -80 dB floor and amin
+    a = audio.audio_complete(wf, 2048)
+    o = oa.AudioCompleteOracle(wf, 2048)
+    D, Do = a.D, o.D
+    assert D.shape == Do.shape == (1025, 61)
+    assert np.abs(D - Do).max() < 2e-3                       # dB; float32 log10 of float32 magnitudes
+    assert D.max() <= 1e-4 and abs(D.min() + 80.0) < 1e-3 and (D <= -79.99).mean() > 0.2
+    # a different reference level, and no floor, through the batched entry point
+    import torch
+    m = a._dev('mag')[None]
+    ref = torch.tensor([0.37], device='cuda')
+    got = audio.amplitude_to_db(m, ref, 1025, top_db=None)[0].cpu().numpy()[:, :1025].T
+    want = oa.amplitude_to_db(a.mag, ref=0.37, top_db=None)      # same magnitudes: the formula itself
+    assert np.abs(got - want).max() < 2e-4 and want.min() < -90
+    # D -> mag on the device: only D and ph set (util_audio.py:143-145)
+    b = audio.audio_complete(None, 2048)
+    b.ph = o.ph
+    b.D = Do
+    b._ref_mag = o.ref_mag
+    mag_back = b.mag
+    keep = Do > -79.0
+    assert np.abs(mag_back - o.mag)[keep].max() / o.mag.max() < 1e-5
+    # spectral flatness: tone-like signal vs white noise (the reference's render sanity check, > 0.3 = noise)
+    tone = _signal(512 * 60, 6)
+    f_tone = audio.audio_complete(tone, 2048).spectral_flatness()
+    fo_tone = oa.AudioCompleteOracle(tone, 2048).spectral_flatness()
+    assert abs(f_tone - fo_tone) < 1e-4 * max(fo_tone, 1e-3)
+    noise = np.random.default_rng(0).standard_normal(512 * 60).astype(np.float32)
+    fn = audio.audio_complete(noise, 2048).spectral_flatness()
+    fo = oa.AudioCompleteOracle(noise, 2048).spectral_flatness()
+    assert abs(fn - fo) < 1e-4 and fn > 0.3 > f_tone
+
