@@ -148,7 +148,11 @@ class TranscriptionLoop:
         if not self._dev_ready:
             self.setup_device()
         p = self.p
-        b = AudioBatch(wave, p.N, p.H).stft(with_phase=True)
+        # the unit phase is read only by the iSTFT that feeds the CQT heads from iteration 1 on (iteration 0
+        # reads the original samples): with one iteration, or without those heads, it is never stored
+        # (8 F T bytes per window, 57 % of the STFT's traffic)
+        odd_length = wave.shape[-1] % p.H != 0              # then even iteration 0 resynthesises (iterate())
+        b = AudioBatch(wave, p.N, p.H).stft(with_phase=self.needs_phase or (self.needs_wave and odd_length))
         refs = dict(refs or {})
         if 'ref_mag' not in refs:
             refs['ref_mag'] = b.ref_max.clone()
@@ -162,6 +166,14 @@ class TranscriptionLoop:
                 refs['ref_C_foc'] = self._cqt_max(b.wave, self.tab_reff, self.tab_reff[0].shape[0], b.T)
         self.refs = refs
         return b
+
+    @property
+    def needs_wave(self):
+        return any(h in self.heads for h in ('pitch', 'instrument', 'velocity'))
+
+    @property
+    def needs_phase(self):
+        return self.iters > 1 and self.needs_wave
 
     def iterate(self, b, it, events, window0=0):
         p = self.p

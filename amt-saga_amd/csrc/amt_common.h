@@ -23,11 +23,22 @@ extern thread_local char amt_hip_err_buf[256];
 #define AMT_LAUNCH_CHECK() AMT_HIP_CHECK(hipGetLastError())
 
 // ---- complex helpers ---------------------------------------------------------
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Written on clang's native 2-vectors so that the backend selects the packed FP32 instructions of
+// CDNA3/4 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: both halves of a complex number per lane and
+// instruction).  The FFT kernels are bound by vector-instruction issue, not by LDS or HBM (a 2048-point
+// transform costs ~2600 issue cycles per SIMD in scalar form), so halving the instruction count of the
+// butterflies is what moves them.
+typedef float amt_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ amt_v2 v2(float2 a) { return amt_v2{a.x, a.y}; }
+__device__ __forceinline__ float2 f2(amt_v2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return f2(v2(a) + v2(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return f2(v2(a) - v2(b)); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    // (ax bx - ay by, ax by + ay bx) = ax * (bx, by) + ay * (-by, bx)
+    const amt_v2 t = amt_v2{a.y, a.y} * amt_v2{-b.y, b.x};
+    return f2(amt_v2{a.x, a.x} * v2(b) + t);
 }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return f2(v2(a) * amt_v2{s, s}); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // multiply by -i : (x + iy)(-i) = y - ix
 __device__ __forceinline__ float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }

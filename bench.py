@@ -14,9 +14,15 @@ Weak scaling: every rank processes the same number of windows.
 Prints ONE JSON line on rank 0 with the driver contract plus
   roofline      dominant kernel (timing-head convolution on the matrix pipe): achieved TFLOP/s from
                 HIP events recorded around every conv launch inside the timed region
-  roofline_stft the north-star HBM kernel pair (STFT->mag/phase/max, subtract):
-                algorithmic GB/s from HIP events on the launch stream
-  cpu_baseline  the numpy oracle ("port") timed on this host on a bounded sample
+  roofline_stft the north-star HBM kernel pair (STFT->mag(/phase)/max, subtract): algorithmic GB/s over the
+                bytes the step CONSUMES (no phase plane when no iteration reads it), HIP events on the launch stream
+  cpu_baseline  the numpy oracle ("port") timed on this host on a bounded sample: one process x one thread,
+                and a multiprocessing Pool (one window per task, one BLAS thread each: the reference's
+                worker model, training.py:623-630)
+  value_f32_mfma          the same step with the strict-f32 convolutions (--conv-mode 0), same run
+  value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
+                          (SURVEY 8d defines the metric including that copy; never `value`)
+  prepare_ms              the untimed per-batch set-up (STFT + song-level CQT normalisers)
 """
 import argparse
 import json
@@ -63,60 +69,109 @@ def build(workload, B):
     return p, loop
 
 
-def cpu_baseline(p, workload, loop, wave_cpu, refs_cpu, budget_s):
-    """Oracle loop on the host cores: same algorithm, same weights, same inputs."""
+def _cpu_worker_setup(wl_name, n_fft):
+    """Build the oracle loop in a process that never touches the GPU (host-side objects only: the
+    product loop is constructed for its seeded weights, never set up on a device)."""
     from oracle.loop import LoopOracle
     from amt_saga import synth
-    try:
-        from threadpoolctl import threadpool_info
-        thr = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
-    except Exception:
-        thr = os.cpu_count() or 1
-    weights = {k: n.weights for k, n in loop.nets.items()}
-    bank = synth.guess_bank_waves(workload['groups'], p.pitch_low, p.pitch_high, sr=p.sr).numpy() \
-        if workload['subtract'] else None
+    from amt_saga.hyperparams import Hyperparams
+    from amt_saga.loop import TranscriptionLoop
+    wl = WORKLOADS[wl_name]
+    p = Hyperparams(N=n_fft)
+    loop = TranscriptionLoop(p, heads=wl['heads'], iters=wl['iters'], subtract=wl['subtract'], groups=wl['groups'])
+    bank = synth.guess_bank_waves(wl['groups'], p.pitch_low, p.pitch_high, sr=p.sr).numpy() if wl['subtract'] else None
     remap = np.zeros(3, np.int32)
-    for i, g in enumerate(workload['groups']):
+    for i, g in enumerate(wl['groups']):
         remap[g] = i
-    orc = LoopOracle(p, workload['heads'], weights, iters=workload['iters'],
-                     subtract=workload['subtract'],
-                     prog_group=remap[synth.prog_group_table(p.instrument_classes)], bank_waves=bank)
-    # The oracle's GEMMs are small: one BLAS thread per logical core of a many-core host is slower than
-    # a smaller pool.  Probe a few pool sizes on the first window and time the sample with the best one.
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        threadpool_limits = None
+    return LoopOracle(p, wl['heads'], {k: n.weights for k, n in loop.nets.items()}, iters=wl['iters'],
+                      subtract=wl['subtract'], prog_group=remap[synth.prog_group_table(p.instrument_classes)],
+                      bank_waves=bank)
 
-    def run(i):
-        refs = {k: v[i] for k, v in refs_cpu.items()}   # song-level constants are inputs (not timed)
-        t0 = time.perf_counter()
-        orc.run_window(wave_cpu[i], refs, i)
-        return time.perf_counter() - t0
 
-    run(0)                                               # first call: BLAS start-up, page faults
-    best_thr, probe = int(thr), {}
-    if threadpool_limits is not None:
-        for cand in sorted({c for c in (8, 16, 32, 64, int(thr)) if c <= int(thr)}):
-            with threadpool_limits(limits=cand):
-                probe[cand] = run(0)
-        best_thr = min(probe, key=probe.get)
-    done, t_total = 0, 0.0
-    ctx = threadpool_limits(limits=best_thr) if threadpool_limits is not None else None
+_ORC = None
+_DATA = None
+
+
+def _cpu_pool_init(wl_name, n_fft, path):
+    global _ORC, _DATA
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(limits=1)
+    _ORC = _cpu_worker_setup(wl_name, n_fft)
+    _DATA = np.load(path)
+
+
+def _cpu_pool_task(i):
+    refs = {k[4:]: _DATA[k][i] for k in _DATA.files if k.startswith('ref_')}
+    t0 = time.perf_counter()
+    _ORC.run_window(_DATA['wave'][i], refs, i)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_main(wl_name, n_fft, path, budget_s):
+    """Runs in a child process started by bench.py (no GPU initialised here, so forking a Pool is safe).
+    Leg 1: one process, every numeric library pinned to ONE thread.  Leg 2: multiprocessing.Pool over the
+    host cores this job may use, one window per task, one BLAS thread per worker."""
+    import multiprocessing as mp
+    from threadpoolctl import threadpool_limits
+    data = np.load(path)
+    n = data['wave'].shape[0]
     try:
-        for i in range(wave_cpu.shape[0]):
-            t_total += run(i)
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    out = {}
+    with threadpool_limits(limits=1):
+        orc = _cpu_worker_setup(wl_name, n_fft)
+        refs0 = {k[4:]: data[k][0] for k in data.files if k.startswith('ref_')}
+        orc.run_window(data['wave'][0], refs0, 0)                     # first call: page faults, BLAS start-up
+        done, t_total = 0, 0.0
+        for i in range(n):
+            refs = {k[4:]: data[k][i] for k in data.files if k.startswith('ref_')}
+            t0 = time.perf_counter()
+            orc.run_window(data['wave'][i], refs, i)
+            t_total += time.perf_counter() - t0
             done += 1
-            if t_total > budget_s:
+            if t_total > budget_s / 2:
                 break
-    finally:
-        if ctx is not None:
-            ctx.restore_original_limits()
-    return dict(value=done / t_total, unit='windows/s', cores=int(best_thr), kind='port',
-                sample='%d window(s) of the same workload, numpy/OpenBLAS oracle (oracle/loop.py), %.1f s of CPU '
-                       'work with the fastest BLAS pool of %s threads (s per window: %s); host has %d logical cores'
-                       % (done, t_total, sorted(probe) or [int(thr)],
-                          ', '.join('%d: %.2f' % (c, probe[c]) for c in sorted(probe)), os.cpu_count() or 0))
+    out['single'] = dict(value=done / t_total, unit='windows/s', cores=1, kind='port',
+                         sample='%d window(s) of the same workload, numpy oracle (oracle/loop.py), 1 process x 1 thread, '
+                                '%.1f s of CPU work' % (done, t_total))
+    # the GPU box grants this job a share of its cores (16 per GPU); more workers than that only queue
+    workers = max(1, min(avail, int(os.environ.get('AMT_CPU_WORKERS', '16'))))
+    per_win = t_total / done
+    tasks = int(min(n, max(workers, workers * max(1, int(budget_s / 2 / max(per_win, 1e-3))))))
+    ctx = mp.get_context('fork')
+    with ctx.Pool(workers, initializer=_cpu_pool_init, initargs=(wl_name, n_fft, path)) as pool:
+        pool.map(_cpu_pool_task, range(min(workers, n)))               # warm every worker
+        t0 = time.perf_counter()
+        pool.map(_cpu_pool_task, [i % n for i in range(tasks)], chunksize=1)
+        wall = time.perf_counter() - t0
+    out['pool'] = dict(value=tasks / wall, unit='windows/s', cores=workers, kind='port',
+                       sample='%d window task(s) of the same workload over multiprocessing.Pool(%d), one window per task, '
+                              'one BLAS thread per worker (training.py:623-630 worker model), %.1f s wall; host has %d '
+                              'logical cores, %d usable by this process' % (tasks, workers, wall, os.cpu_count() or 0, avail))
+    print('CPU_BASELINE ' + json.dumps(out), flush=True)
+
+
+def cpu_baseline(p, wl_name, wave_cpu, refs_cpu, budget_s):
+    """Oracle loop on the host cores: same algorithm, same weights, same inputs, in a child process."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'cpu_sample.npz')
+        np.savez(path, wave=wave_cpu, **{'ref_' + k: v for k, v in refs_cpu.items()})
+        env = dict(os.environ)
+        env.pop('RANK', None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', wl_name, str(p.N), path,
+                            str(budget_s)], capture_output=True, text=True, env=env, timeout=600)
+    for line in r.stdout.splitlines():
+        if line.startswith('CPU_BASELINE '):
+            legs = json.loads(line[len('CPU_BASELINE '):])
+            best = legs['pool']
+            best = dict(best)
+            best['single_thread'] = legs['single']
+            return best
+    raise RuntimeError('cpu baseline worker failed: ' + r.stderr[-2000:])
 
 
 def main():
@@ -126,8 +181,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--windows', type=int, default=0, help='windows per GPU (default: the workload size)')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-seconds', type=float, default=24.0, help='CPU work of the baseline sample (both legs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the f32-MFMA and H2D-inclusive legs (profiling runs)')
     ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1, 2),
                     help='convolution arithmetic: 2 = split-fp16 (default), 1 = split-bf16, 0 = f32 MFMA; all f32-equivalent')
     args = ap.parse_args()
@@ -150,15 +207,34 @@ def main():
     wave, _ = synth.make_windows(B, L, seed=wl['seed'] * 1000 + rank, notes_per_window=wl['notes'],
                                  groups=wl['groups'], sr=p.sr, device=dev)
     window0 = rank * B
-    # song-level constants once per batch (training.py:269-282 computes them once per song)
+    # song-level constants once per batch (training.py:269-282 computes them once per song): untimed set-up,
+    # reported as prepare_ms
     loop.prepare(wave)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.prepare(wave)
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t0) * 1e3
     refs = loop.refs
     timing_nets = [loop.nets[k] for k in ('timing_start', 'timing_end') if k in loop.nets]
     prof_nets = timing_nets or list(loop.nets.values())
 
-    def step():
-        ev, b = loop.run(wave, window0=window0, refs=refs)
+    def step(w=wave):
+        ev, b = loop.run(w, window0=window0, refs=refs)
         return adist.gather_events(ev.reshape(-1, 7), n_total=B * world * wl['iters']), b
+
+    def timed_steps(n, fn):
+        """n steps bracketed by barrier + synchronize, max over ranks -> seconds."""
+        adist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = None
+        for _ in range(n):
+            out = None                  # release the previous batch first: the caching allocator then reuses
+            out = fn()                  # its blocks instead of hipMalloc-ing inside the timed region
+        torch.cuda.synchronize()
+        adist.barrier()
+        return adist.max_over_ranks(time.perf_counter() - t), out
 
     for _ in range(args.warmup):
         step()
@@ -176,23 +252,13 @@ def main():
             e0.record()
             r = fn(self, *a, **k)
             e1.record()
-            ev_pairs.append((tag, e0, e1))
+            ev_pairs.append((tag, e0, e1, self.ph is not None if tag == 'stft' else None))
             return r
         return w
     AudioBatch.stft, AudioBatch.subtract = timed(orig_stft, 'stft'), timed(orig_sub, 'subtract')
 
-    adist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    events = last = None
-    for _ in range(args.steps):
-        events = last = None            # release the previous batch first: the caching allocator then
-        events, last = step()           # reuses its blocks instead of hipMalloc-ing inside the timed region
-    torch.cuda.synchronize()
-    adist.barrier()
-    dt = time.perf_counter() - t0
+    dt, (events, last) = timed_steps(args.steps, step)
     AudioBatch.stft, AudioBatch.subtract = orig_stft, orig_sub
-    dt = adist.max_over_ranks(dt)
     value = B * world * args.steps / dt
 
     # ---- roofline of the dominant kernel (HIP events around every conv launch) -------------
@@ -213,22 +279,24 @@ def main():
     achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
     split = conv_mode >= 1 and dom_key[2] <= 64
     nmf = 3 if conv_mode == 2 else 6                       # MFMAs per f32-equivalent product block
-    # split-bf16: every algorithmic f32 MAC costs six bf16 MFMA MACs, so the MFMA roof for the
-    # ALGORITHMIC flops of this kernel is the dense bf16 peak / 6
+    # split modes: every algorithmic f32 MAC costs nmf f16 / bf16 MFMA MACs, so the MFMA roof for the
+    # ALGORITHMIC flops of this kernel is the dense 16-bit peak / nmf
     peak_tf = round(MFMA_BF16_PEAK_TF / nmf, 1) if split else MFMA_F32_PEAK_TF
     if split and conv_mode == 2 and dom_key[3] == 32:
         kname = ('conv_f16x3s_kernel<%d,%d,%d> (Cout %d) on %dx%d (3 x v_mfma_f32_16x16x32_f16 per f32 product '
                  'block of a tap pair)') % dom_key
     else:
-        kname = (('conv_f16x3_kernel<%d,%d,%d,%d> on %dx%d (3 x v_mfma_f32_32x32x16_f16 per f32 product block)'
+        kname = (('conv_f16x3s_kernel<%d,%d,%d> (Cout %d, 32-wide N-slices) on %dx%d (3 x v_mfma_f32_16x16x32_f16 per f32 product block)'
                   if conv_mode == 2 else
                   'conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)')
                  if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    pmc = {}
     if os.path.exists(tf):
         try:
-            t = json.load(open(tf)).get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
+            pmc = json.load(open(tf))
+            t = pmc.get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
             if t:
                 traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 512))
         except Exception:
@@ -241,35 +309,70 @@ def main():
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2))
+    # ---- the north star's HBM pair: only the bytes the step consumes ------------------------
     F, T, ldf = p.N // 2 + 1, p.timing_frames, (p.N // 2 + 1 + 3) & ~3
-    stft_ms = sum(e0.elapsed_time(e1) for tag, e0, e1 in ev_pairs if tag == 'stft')
-    sub_ms = sum(e0.elapsed_time(e1) for tag, e0, e1 in ev_pairs if tag == 'subtract')
-    n_stft = sum(1 for tag, _, _ in ev_pairs if tag == 'stft')
-    n_sub = sum(1 for tag, _, _ in ev_pairs if tag == 'subtract')
-    stft_bytes = B * (4 * L + 4 * F * T + 8 * F * T)                    # wave in, mag + unit phase out
+    stft_ms = sum(e0.elapsed_time(e1) for tag, e0, e1, _ in ev_pairs if tag == 'stft')
+    sub_ms = sum(e0.elapsed_time(e1) for tag, e0, e1, _ in ev_pairs if tag == 'subtract')
+    n_stft = sum(1 for tag, _, _, _ in ev_pairs if tag == 'stft')
+    n_sub = sum(1 for tag, _, _, _ in ev_pairs if tag == 'subtract')
+    with_phase = any(ph for tag, _, _, ph in ev_pairs if tag == 'stft')
+    stft_bytes = B * (4 * L + 4 * F * T + (8 * F * T if with_phase else 0))     # wave in, mag (+ unit phase) out
     sub_bytes = B * (2 * 4 * F * T + 4 * F * loop.bank_frames) if n_sub else 0
     hbm_ms = stft_ms + sub_ms
     hbm_gbs = (n_stft * stft_bytes + n_sub * sub_bytes) / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else 0.0
     stft_traffic = None
-    if os.path.exists(tf):
-        try:
-            t = json.load(open(tf))
-            stft_traffic = int((t['stft']['hbm_bytes_per_window_per_launch'] +
-                                (t['subtract']['hbm_bytes_per_window_per_launch'] if n_sub else 0)) * B)
-        except Exception:
-            stft_traffic = None
+    try:
+        key = 'stft' if with_phase else 'stft_mag_only'
+        stft_traffic = int((pmc[key]['hbm_bytes_per_window_per_launch'] +
+                            (pmc['subtract']['hbm_bytes_per_window_per_launch'] if n_sub else 0)) * B)
+    except Exception:
+        stft_traffic = None
     roofline_stft = dict(bound='hbm', achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                          frac=round(hbm_gbs / HBM_PEAK_GBS, 4), traffic=stft_traffic,
                          algorithmic_bytes=int(stft_bytes + sub_bytes),
-                         kernel='stft_mag_kernel<2048,phase> + subtract_kernel',
+                         kernel='stft_mag_kernel<2048,%s> + subtract_kernel' % ('phase' if with_phase else 'mag only'),
+                         phase_plane_stored=bool(with_phase),
                          stft_gbs=round(n_stft * stft_bytes / (stft_ms * 1e-3) / 1e9, 1) if stft_ms else None,
                          subtract_gbs=round(n_sub * sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
                          ms_per_step=round(hbm_ms / args.steps, 3))
 
+    # ---- extra legs, same run ----------------------------------------------------------------
+    extras = {}
+    if not args.no_extras:
+        # (1) strict-f32 convolutions
+        if conv_mode != 0 and loop.nets:
+            for n in loop.nets.values():
+                n.set_mode(0)
+            step()
+            k0 = max(1, min(args.steps, 3))
+            dt0, _ = timed_steps(k0, step)
+            extras['value_f32_mfma'] = round(B * world * k0 / dt0, 2)
+            for n in loop.nets.values():
+                n.set_mode(conv_mode)
+            step()
+        # (2) host -> HBM copy of the batch's audio inside the timed region (pinned host memory, one copy
+        # per step on the launch stream, no overlap with compute)
+        host = torch.empty((B, L), dtype=torch.float32).pin_memory()
+        host.copy_(wave)
+        stage = torch.empty_like(wave)
+
+        def step_h2d():
+            stage.copy_(host, non_blocking=True)
+            return step(stage)
+        step_h2d()
+        k1 = max(1, min(args.steps, 5))
+        dt1, _ = timed_steps(k1, step_h2d)
+        extras['value_h2d_inclusive'] = round(B * world * k1 / dt1, 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); stage.copy_(host, non_blocking=True); e1.record(); torch.cuda.synchronize()
+        extras['h2d_gbs'] = round(B * L * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del host, stage
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        refs_cpu = {k: v[:40].cpu().numpy() for k, v in refs.items()}
-        cpu = cpu_baseline(p, wl, loop, wave[:40].cpu().numpy(), refs_cpu, args.cpu_seconds)
+        n_cpu = min(B, 64)
+        refs_cpu = {k: v[:n_cpu].cpu().numpy() for k, v in refs.items()}
+        cpu = cpu_baseline(p, args.workload, wave[:n_cpu].cpu().numpy(), refs_cpu, args.cpu_seconds)
 
     if rank == 0:
         out = {
@@ -279,21 +382,26 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {0: 'f32', 1: 'f32 (conv: split-bf16 x3 operands, f32 accumulate)',
                       2: 'f32 (conv: split-fp16 x2 operands, f32 accumulate)'}[conv_mode],
-            'data': 'synthetic (additive-synth windows, seeded random-init weights)',
+            'data': 'synthetic (additive-synth windows, seeded synthetic weights with calibrated BN statistics)',
             'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
                        'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
                        'parallelism': 'windows sharded x%d, event all-gather' % world},
             'roofline': roofline, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
+            'prepare_ms': round(prepare_ms, 1),
             'events_checksum': int(events.to(torch.int64).sum().item()),
+            'distinct_decisions': {k: int(torch.unique(events[:, c]).numel())
+                                   for c, k in ((2, 'pitch'), (4, 'velocity'), (5, 'onset_frame'), (6, 'end_frame'))},
             'arithmetic_note': {
                 0: 'convolutions on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)',
                 1: 'f32-equivalent: every f32 operand split exactly into 3 bf16 terms, 6 MFMAs per product '
                    'block, f32 accumulate; same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py)',
-                2: 'f32-equivalent: every f32 operand = f16 h + 2^-11 f16 l (22 significand bits, power-of-two '
-                   'range scaling), 3 MFMAs per product block, f32 accumulate, ~1e-7 rms / <= 2^-21 worst case per product; '
-                   'same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py); --conv-mode 0 runs the f32 MFMA',
+                2: 'f32-equivalent: every f32 operand = f16 h + 2^-11 f16 l (22 significand bits, per-window power-of-two '
+                   'range scaling from measured maxima), 3 MFMAs per product block, f32 accumulate, ~1e-7 rms / <= 2^-21 '
+                   'worst case per product; same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py); value_f32_mfma '
+                   'is the same step on the f32 MFMA',
             }[conv_mode],
         }
+        out.update(extras)
         if cpu:
             out['speedup_vs_cpu_baseline'] = round(value / cpu['value'], 1)
         print(json.dumps(out), flush=True)
@@ -301,4 +409,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-baseline-worker':
+        cpu_baseline_main(sys.argv[2], int(sys.argv[3]), sys.argv[4], float(sys.argv[5]))
+    else:
+        main()
