@@ -283,6 +283,14 @@ class res_net:
             pass
 
     def load_weights(self, filename):                       # RDCNN.py:778-782
+        """The reference's checkpoints are Keras ``save_weights`` HDF5 files ('.h5', RDCNN.py:490-494): read
+        by the pure-Python importer (keras_io / hdf5).  '.npz' = this build's own save_weights()."""
+        with open(filename, 'rb') as fh:
+            magic = fh.read(8)
+        if magic == b'\x89HDF\r\n\x1a\n':
+            from .keras_io import load_keras_weights
+            self.set_weights(load_keras_weights(filename, self.layout))
+            return
         with np.load(filename) as z:
             self.set_weights({k: z[k] for k in z.files})
 

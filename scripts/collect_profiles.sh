@@ -14,14 +14,19 @@ export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- \
-    python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_kernel_trace.json 2> $OUT/ks.err
+    python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_kernel_trace.json 2> $OUT/ks.err
 cp /tmp/prof_ks/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 python3 $R/scripts/summarize_trace.py /tmp/prof_ks $OUT/kernel_trace_summary.csv >> $OUT/ks.err 2>&1
 # counters in their own passes, nothing but --pmc (+ kernel names come with the counter csv)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -- \
-    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pf.err
+    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline --no-extras > $OUT/bench_pmc_fetch.json 2> $OUT/pf.err
 python3 $R/scripts/summarize_pmc.py /tmp/prof_f FETCH_SIZE $OUT/pmc_fetch.csv >> $OUT/pf.err 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -- \
-    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pw.err
+    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline --no-extras > $OUT/bench_pmc_write.json 2> $OUT/pw.err
 python3 $R/scripts/summarize_pmc.py /tmp/prof_w WRITE_SIZE $OUT/pmc_write.csv >> $OUT/pw.err 2>&1
+# C5's per-GPU shard: 2048 windows, all heads, 5 iterations (kernel trace only)
+rm -rf /tmp/prof_c5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -- \
+    python3 $R/bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_c5_kernel_trace.json 2> $OUT/c5.err
+cp /tmp/prof_c5/*/*_kernel_stats.csv $OUT/kernel_stats_c5.csv 2>/dev/null
 ls -la $OUT

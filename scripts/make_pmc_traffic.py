@@ -14,7 +14,8 @@ windows = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false>',
             'conv_bf16x6': 'conv_bf16x6_kernel<4, 16, 32, 32, false>',
             'conv_mfma': 'conv_mfma_kernel<4, 16, 32, 32',
-            'stft': 'stft_mag_kernel<2048, true>', 'subtract': 'subtract_kernel'}
+            'stft': 'stft_mag_kernel<2048, true>', 'stft_mag_only': 'stft_mag_kernel<2048, false>',
+            'subtract': 'subtract_kernel'}
 
 
 def load(path):
