@@ -12,12 +12,11 @@ benchmark windows and (b) the guess-template bank the subtraction step reads.
     window scaling follows render() (:778-781):
         wf * (vel_max/128)**4 / max|wf|,  vel_max - 12 for a single note
 
-Two implementations of the same definition:
-  * render_window(): torch float64 on the CPU -- the synth's specification, used by the
-    CPU tests and as the checker for the kernel;
-  * render_windows_device(): the HIP kernel amt_synth_windows (csrc/amt_synth.hip) --
-    what the benchmark, the guess bank and the loop's "render" guess mode run.  It raises
-    without a GPU like every other product path.
+This module holds the definition's constants, the note-list generation (host integers) and the
+device renderer render_windows_device() = the HIP kernel amt_synth_windows (csrc/amt_synth.hip): what
+the benchmark, the guess bank and the loop's "render" guess mode run.  It raises without a GPU like
+every other product path.  The float64 CPU restatement of the same definition, used as the kernel's
+checker and by the CPU baseline, lives in oracle/synth.py.
 """
 import numpy as np
 import torch
@@ -44,46 +43,6 @@ def program_to_group(program):
 
 def prog_group_table(n_prog=112):
     return np.array([program_to_group(p) for p in range(n_prog)], dtype=np.int32)
-
-
-def _note(t, group, pitch, onset, dur, sr):
-    """t: [L] float64 tensor of seconds; returns float64 [L]."""
-    pr = PRESETS[PROGRAM_GROUPS[group]]
-    f0 = 440.0 * 2.0 ** ((pitch - 69) / 12.0)
-    tt = t - onset
-    on = (tt >= 0).to(t.dtype)
-    ttc = torch.clamp(tt, min=0.0)
-    env = torch.clamp(ttc / pr['attack'], max=1.0)
-    if pr['tau'] is not None:
-        env = env * torch.exp(-ttc / pr['tau'])
-    rel = torch.clamp(tt - dur, min=0.0)
-    env = env * torch.exp(-rel / RELEASE_TAU) * on
-    env = env * (tt < dur + TAIL_SECONDS).to(t.dtype)
-    y = torch.zeros_like(t)
-    for h in range(1, pr['H'] + 1):
-        if h * f0 >= sr / 2:
-            break
-        y = y + (h ** -pr['slope']) * torch.sin(2.0 * np.pi * h * f0 * ttc)
-    return y * env
-
-
-def render_window(notes, L, sr=44100, device='cpu'):
-    """notes: list of (group, pitch, velocity, onset_s, dur_s).  float32 [L]."""
-    t = torch.arange(L, dtype=torch.float64, device=device) / sr
-    wf = torch.zeros(L, dtype=torch.float64, device=device)
-    for (g, p, v, t0, d) in notes:
-        # note records are float32 (the [B, M, 5] tensor the kernel reads): onset and duration
-        # take their float32 values here too, so both implementations see the same note
-        t0, d = float(np.float32(t0)), float(np.float32(d))
-        amp = (v / 128.0) ** 4          # fluidsynth-like loudness spread between notes
-        wf = wf + amp * _note(t, g, p, t0, d, sr)
-    vel_max = max(n[2] for n in notes)
-    if len(notes) == 1:
-        vel_max = max(1, vel_max - 12)
-    peak = wf.abs().max()
-    if float(peak) > 0:
-        wf = wf * ((vel_max / 128.0) ** 4 / peak)
-    return wf.to(torch.float32)
 
 
 def notes_tensor(notes, max_notes=None):
@@ -129,25 +88,36 @@ def random_notes(rng, n_notes, groups=(0,), max_onset=3.0):
     return out
 
 
-def make_windows(B, L, seed, notes_per_window=(3, 3), groups=(0,), sr=44100, device='cpu',
-                 max_onset=3.0):
-    """[B, L] float32 tensor of synthetic windows + the note lists."""
+def window_notes(B, seed, notes_per_window=(3, 3), groups=(0,), max_onset=3.0):
+    """The seeded note lists of B synthetic windows (host integers / floats only)."""
     rng = np.random.default_rng(seed)
     notes = []
     for _ in range(B):
         n = int(rng.integers(notes_per_window[0], notes_per_window[1] + 1))
         notes.append(random_notes(rng, n, groups, max_onset))
-    if _on_gpu(device):
-        return render_windows_device(notes, L, sr), notes
-    return torch.stack([render_window(ns, L, sr, device) for ns in notes]), notes
+    return notes
+
+
+def bank_notes(groups=(0,), pitch_lo=21, pitch_hi=108, dur=1.0, velocity=100):
+    """One single-note guess per (group, pitch) -- the guess-template bank."""
+    return [[(g, p, velocity, 0.0, dur)] for g in groups for p in range(pitch_lo, pitch_hi + 1)]
+
+
+def make_windows(B, L, seed, notes_per_window=(3, 3), groups=(0,), sr=44100, device='cuda',
+                 max_onset=3.0):
+    """[B, L] float32 device tensor of synthetic windows + the note lists."""
+    notes = window_notes(B, seed, notes_per_window, groups, max_onset)
+    if not _on_gpu(device):
+        raise RuntimeError('amt_saga.synth renders on the GPU only (the CPU restatement is oracle/synth.py)')
+    return render_windows_device(notes, L, sr), notes
 
 
 def guess_bank_waves(groups=(0,), pitch_lo=21, pitch_hi=108, dur=1.0, velocity=100, sr=44100,
-                     device='cpu'):
+                     device='cuda'):
     """One rendered single-note guess per (group, pitch): [G*n_pitch, L_g] float32,
     L_g = (dur + 1 s tail) * sr samples (the reference's guess = note + 1 s, :876)."""
     Lg = int(round((dur + TAIL_SECONDS) * sr))
-    notes = [[(g, p, velocity, 0.0, dur)] for g in groups for p in range(pitch_lo, pitch_hi + 1)]
-    if _on_gpu(device):
-        return render_windows_device(notes, Lg, sr)
-    return torch.stack([render_window(ns, Lg, sr, device) for ns in notes])
+    notes = bank_notes(groups, pitch_lo, pitch_hi, dur, velocity)
+    if not _on_gpu(device):
+        raise RuntimeError('amt_saga.synth renders on the GPU only (the CPU restatement is oracle/synth.py)')
+    return render_windows_device(notes, Lg, sr)

@@ -73,13 +73,14 @@ def _cpu_worker_setup(wl_name, n_fft):
     """Build the oracle loop in a process that never touches the GPU (host-side objects only: the
     product loop is constructed for its seeded weights, never set up on a device)."""
     from oracle.loop import LoopOracle
+    from oracle import synth as osynth
     from amt_saga import synth
     from amt_saga.hyperparams import Hyperparams
     from amt_saga.loop import TranscriptionLoop
     wl = WORKLOADS[wl_name]
     p = Hyperparams(N=n_fft)
     loop = TranscriptionLoop(p, heads=wl['heads'], iters=wl['iters'], subtract=wl['subtract'], groups=wl['groups'])
-    bank = synth.guess_bank_waves(wl['groups'], p.pitch_low, p.pitch_high, sr=p.sr).numpy() if wl['subtract'] else None
+    bank = osynth.guess_bank_waves(wl['groups'], p.pitch_low, p.pitch_high, sr=p.sr) if wl['subtract'] else None
     remap = np.zeros(3, np.int32)
     for i, g in enumerate(wl['groups']):
         remap[g] = i

@@ -19,7 +19,7 @@ Only those small tensors (BN parameters, last Dense) are stored, keyed by topolo
 operators (oracle/rdcnn.py) -- this is offline fixture generation, like training would be, and nothing
 in the product path executes it.
 
-Calibration features come from the CPU synthesiser (amt_saga.synth.render_window) through the oracle's
+Calibration features come from the CPU synthesiser (oracle.synth.render_window) through the oracle's
 feature recipe: C_timing for the timing heads; CQT slices at random (onset, end) for pitch / instrument /
 velocity, of the window and of a partly subtracted residual.
 """
@@ -32,7 +32,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'amt-saga_amd')]
 
-from oracle import audio as oa, cqt as ocqt, rdcnn as orc          # noqa: E402
+from oracle import audio as oa, cqt as ocqt, rdcnn as orc, synth as osynth   # noqa: E402
 from amt_saga import heads as H, synth                              # noqa: E402
 from amt_saga.hyperparams import Hyperparams                        # noqa: E402
 from amt_saga.rdcnn import topology_signature                       # noqa: E402
@@ -102,9 +102,8 @@ def calibrate(w, cfg, xs, role, seed):
 
 def windows(p, n, seed, groups):
     L = p.H * (p.timing_frames - 1)
-    wave, _ = synth.make_windows(n, L, seed=seed, notes_per_window=(1, 4), groups=groups, sr=p.sr,
-                                 max_onset=0.5 * p.window_size_note_time)
-    return wave.numpy()
+    notes = synth.window_notes(n, seed, (1, 4), groups, 0.5 * p.window_size_note_time)
+    return osynth.render_notes(notes, L, p.sr)
 
 
 def timing_features(p, n, seed):

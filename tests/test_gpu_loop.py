@@ -50,7 +50,8 @@ def _run_case(env, p, heads, iters, B, seed, groups=(0,), subtract=True, tweak=N
     events, b = lp.run(wave, window0=100)
     ev = events.cpu().numpy()
     assert ev.shape == (iters, B, 7)
-    bank = synth.guess_bank_waves(groups, p.pitch_low, p.pitch_high, sr=p.sr).numpy() if subtract else None
+    from oracle import synth as osynth
+    bank = osynth.guess_bank_waves(groups, p.pitch_low, p.pitch_high, sr=p.sr) if subtract else None
     remap = np.zeros(3, np.int32)
     for i, g in enumerate(groups):
         remap[g] = i

@@ -1,5 +1,5 @@
 """GPU: the HIP note synthesiser (amt_synth_windows) against its float64 CPU
-specification (amt_saga/synth.py:render_window), and the loop's 'render' guess
+specification (oracle/synth.py:render_window), and the loop's 'render' guess
 mode (one synthesised guess per decision, training.py:421-431) against the
 oracle loop given the CPU synth as its guess function."""
 import numpy as np
@@ -17,6 +17,9 @@ def env():
     return dict(torch=torch, synth=synth, loop=loop, hp=hyperparams, oloop=oloop)
 
 
+from oracle import synth as osynth      # noqa: E402  (the float64 CPU restatement of the synth definition)
+
+
 def test_synth_kernel_vs_cpu_definition(env):
     synth, torch = env['synth'], env['torch']
     rng = np.random.default_rng(5)
@@ -27,7 +30,7 @@ def test_synth_kernel_vs_cpu_definition(env):
     notes.append([(2, 60, 64, 0.25, 0.1), (2, 60, 64, 0.25, 0.1)])   # identical notes
     got = synth.render_windows_device(notes, L, sr).cpu().numpy()
     for i, ns in enumerate(notes):
-        want = synth.render_window(ns, L, sr).numpy()
+        want = osynth.render_window(ns, L, sr).numpy()
         peak = np.abs(want).max()
         assert peak > 0
         assert np.abs(got[i] - want).max() / peak < 2e-5, i
@@ -77,7 +80,7 @@ def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
     def guess_fn(program, pitch, velocity, frames):
         dur = min(float(np.float32(frames) * np.float32(p.H / p.sr)), 1.0)
         vel = velocity if velocity > 0 else 100
-        return synth.render_window([(int(table[program]), pitch, vel, 0.0, dur)], Lg, p.sr).numpy()
+        return osynth.render_window([(int(table[program]), pitch, vel, 0.0, dur)], Lg, p.sr).numpy()
 
     orc = env['oloop'].LoopOracle(p, heads, {k: n.weights for k, n in lp.nets.items()}, iters=iters,
                                   guess_fn=guess_fn)

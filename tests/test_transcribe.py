@@ -29,7 +29,8 @@ def test_transcribe_flac_to_midi(tmp_path):
     L = p.H * (p.timing_frames - 1)
     n = int(3.2 * L)
     notes_in = [(0, 60, 100, 0.2, 0.5), (0, 64, 90, 0.9, 0.4), (1, 67, 80, 1.6, 0.6), (2, 72, 110, 2.4, 0.3)]
-    wf = synth.render_window(notes_in, n, p.sr).numpy()
+    from oracle import synth as osynth
+    wf = osynth.render_window(notes_in, n, p.sr).numpy()
     path = str(tmp_path / 'clip.flac')
     flac.save_float(wf, path, p.sr)
     back, sr = flac.load_float(path)
