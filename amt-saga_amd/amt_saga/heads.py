@@ -1,8 +1,8 @@
 """The four classifier heads: same class names, constructor arguments and
 classify() contract as /root/reference/pitch_classifier.py:12-57,
 instrumentclassifier.py:11-83, velocity_classifier.py:11-57 and
-timing_classifier.py:13-58.  classify(spec, gold=None) predicts; the train /
-test branches (gold given) are outside the hot path and raise.
+timing_classifier.py:13-58.  classify(spec, gold=None) predicts; with gold it
+trains on the batch, or tests it when test_phase is set (res_net.train / .test).
 
 classify() additionally accepts a device tensor [B, bands, frames] (the batched
 loop keeps features in HBM) and then returns a device tensor."""
@@ -16,9 +16,12 @@ class _Head(res_net):
     _bands = _frames = None
 
     def _classify(self, spec, gold, test_phase):
-        if gold is not None:
-            raise NotImplementedError('train/test (gold given) is outside the hot path; '
-                                      'classify(spec) predicts')
+        if gold is not None:                               # pitch_classifier.py:48-55: test or train on the batch
+            check_shape(spec, self._bands, self._frames)
+            expanded, gold_expanded = list_to_nd_array(spec, gold)
+            if test_phase:
+                return self.test(expanded, gold_expanded, use_predict=True)
+            return self.train(expanded, gold_expanded)
         if isinstance(spec, torch.Tensor):
             if tuple(spec.shape[1:3]) != (self._bands, self._frames):
                 raise ValueError('Invalid Input shape. Expected: {} . Got: {}'.format(

@@ -3,9 +3,9 @@
 Keeps the reference constructor's argument names (RDCNN.py:42-63) and
 ``predict(x)`` (RDCNN.py:591-597); the graph is the one RDCNN.py:176-233
 builds.  The forward pass runs in the HIP library (amt_rdcnn_forward: fp32
-MFMA implicit-GEMM convolutions, fused BN/sigmoid/shortcut epilogues).
-train/test/fit_generator/checkpoint/report/plot are outside the hot path
- and raise NotImplementedError.
+MFMA implicit-GEMM convolutions, fused BN/sigmoid/shortcut epilogues);
+train / test / fit_generator (RDCNN.py:503-589) run amt_trainer_step (training-mode BN, backward,
+Adagrad, MSE / sparse-CCE); report / plot / metrics bookkeeping stay out of scope.
 
 Weights.  The reference ships none; ``init_weights(seed)`` draws synthetic
 ones (Keras initialisers for kernels; BN moving statistics and biases are
@@ -255,6 +255,7 @@ class res_net:
         self._release()
 
     def _ensure(self):
+        self._sync_from_trainer()
         if self._net is not None:
             return
         lib = _lib.load()
@@ -275,6 +276,10 @@ class res_net:
             self._lib.amt_rdcnn_destroy(self._net)
         self._net = None
         self._ws = None
+        if getattr(self, '_trainer', None) is not None:
+            self._tlib.amt_trainer_destroy(self._trainer)
+        self._trainer = None
+        self._trained = False
 
     def __del__(self):
         try:
@@ -369,15 +374,104 @@ class res_net:
     def _scale_activation_to_output(self, x):               # RDCNN.py:308-310
         return ((x - self.out_func_min) / self.out_func_factor) * self.out_val_factor + self.out_val_min
 
-    # ---- training-side API: outside the hot path ---------------------------------
+    # ---- training side (RDCNN.py:503-589): amt_trainer_step on the device ----------------------------
+    def _trainer_handle(self):
+        """The device-side trainer, created from the current weights on first use.  From then on it owns
+        the live weights; predict() pulls them back before its next forward (``_sync_from_trainer``)."""
+        if getattr(self, '_trainer', None) is None:
+            lib = _lib.load()
+            require_gpu()
+            d = self._desc()
+            h = C.c_void_p()
+            _lib.check(lib.amt_trainer_create(C.byref(h), C.byref(d), self._blob.ctypes.data_as(C.c_void_p),
+                                              self._blob.size, float(getattr(self, 'learning_rate', 0.0)),
+                                              float(getattr(self, 'adagrad_epsilon', 0.0))))
+            self._trainer, self._tlib, self._trained = h, lib, False
+        return self._trainer
+
+    def _sync_from_trainer(self):
+        if getattr(self, '_trainer', None) is not None and self._trained:
+            blob = np.empty(self._blob.size, np.float32)
+            _lib.check(self._tlib.amt_trainer_get_weights(self._trainer, blob.ctypes.data_as(C.c_void_p), blob.size))
+            w, off = {}, 0
+            for name, shape in self.layout:
+                n = int(np.prod(shape))
+                w[name] = blob[off:off + n].reshape(shape).copy()
+                off += n
+            self.weights, self._blob = w, blob
+            if self._net is not None:
+                self._lib.amt_rdcnn_destroy(self._net)
+            self._net = None
+            self._trained = False
+
+    def gradients(self):
+        """Gradients of the last train() call as a weight-shaped dict (zeros for BN moving statistics)."""
+        blob = np.empty(self._blob.size, np.float32)
+        _lib.check(self._tlib.amt_trainer_get_grads(self._trainer_handle(), blob.ctypes.data_as(C.c_void_p), blob.size))
+        out, off = {}, 0
+        for name, shape in self.layout:
+            n = int(np.prod(shape))
+            out[name] = blob[off:off + n].reshape(shape).copy()
+            off += n
+        return out
+
+    def _batch(self, x, y, update):
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        dx = []
+        for a in xs:
+            a = a if isinstance(a, torch.Tensor) else np.asarray(a)
+            if a.ndim == 4:
+                a = a[..., 0]
+            dx.append(to_dev(a))
+        B = dx[0].shape[0]
+        yv = np.asarray(y.cpu().numpy() if isinstance(y, torch.Tensor) else y, dtype=np.float64).reshape(-1)
+        if yv.shape[0] != B:
+            raise ValueError('Invalid Input shape. Expected: {} . Got: {}'.format((B,), yv.shape))
+        if self.output_classes == 1:
+            yv = self._scale_output_to_activation(yv)               # RDCNN.py:513-514, :569-570
+        h = self._trainer_handle()
+        K = self.cfg['output_classes']
+        pred = empty((B, K))
+        loss = C.c_float(0.0)
+        arr = (C.c_void_p * len(dx))(*[t.data_ptr() for t in dx])
+        _lib.check(self._tlib.amt_trainer_step(h, arr, ptr(to_dev(yv.astype(np.float32))), B, int(update),
+                                               C.byref(loss), ptr(pred), stream_ptr()))
+        p = pred.cpu().numpy()
+        return float(loss.value), (self._scale_activation_to_output(p) if self.output_classes == 1 else p)
+
     def train(self, x, y):
-        raise NotImplementedError('training is outside the hot path (SURVEY 8f row 4)')
+        """RDCNN.py:503-526: one ``train_on_batch`` (BatchNormalization in training mode, backward, Adagrad;
+        targets scaled to the activation range for a single output).  Returns the prediction of the batch in
+        output scale ((B,1)) or the class probabilities ((B,K)); the loss is appended to ``metrics_train``."""
+        loss, pred = self._batch(x, y, True)
+        self._trained = True
+        self.metrics_train.append([loss])
+        if self.checkpoint_dir and (self.current_batch % self.checkpoint_frequency == 0):
+            self.save_checkpoint()
+        self.current_batch += 1
+        return pred
 
     def test(self, x, y, use_predict=False):
-        raise NotImplementedError('training/test bookkeeping is outside the hot path')
+        """RDCNN.py:559-589: ``test_on_batch`` (inference-mode forward + loss, no update); the loss is appended
+        to ``metrics_test``.  ``use_predict`` only changes the reference's bookkeeping, not the numbers."""
+        loss, pred = self._batch(x, y, False)
+        self.metrics_test.append([loss])
+        return pred
 
-    def fit_generator(self, *a, **k):
-        raise NotImplementedError('training is outside the hot path')
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, **kwargs):   # RDCNN.py:536-556
+        """Keras fit_generator over (x, y) batches: train() on each."""
+        for _ in range(int(epochs)):
+            for step, (xb, yb) in enumerate(generator):
+                self.train(xb, yb)
+                if steps_per_epoch is not None and step + 1 >= steps_per_epoch:
+                    break
 
-    def save_checkpoint(self):
-        raise NotImplementedError('checkpointing is outside the hot path')
+    def save_checkpoint(self):                              # RDCNN.py:467-501
+        """Weights of the current batch index as '<dir>/<prefix>_<batch>.npz' (the reference writes a Keras
+        .h5; this build reads those -- load_weights -- and writes its own .npz)."""
+        import os as _os
+        self._sync_from_trainer()
+        _os.makedirs(self.checkpoint_dir, exist_ok=True)
+        path = _os.path.join(self.checkpoint_dir, '%s_%d.npz' % (self.checkpoint_prefix, self.current_batch))
+        self.save_weights(path)
+        return path

@@ -1,0 +1,803 @@
+// RDCNN training step for gfx950: forward in training mode, backward, Adagrad.
+//
+// Replaces, for the graph of /root/reference/RDCNN.py:176-233, what ``res_net.train`` /
+// ``res_net.test`` run through Keras (RDCNN.py:503-526, :559-589): ``model.train_on_batch`` /
+// ``test_on_batch`` of a model compiled with ``keras.optimizers.Adagrad()`` and
+// ``mean_squared_error`` (one output) or ``sparse_categorical_crossentropy`` (RDCNN.py:245-254).
+// CPU restatement and its pinning (PyTorch autograd): oracle/train.py, tests/test_oracle_train.py.
+//
+// Training runs at the reference's batch sizes (8 windows, main.py -batch_size), far from the
+// inference loop's thousands, so this file favours one small set of exact, deterministic kernels
+// over per-layer fusion:
+//   * every contraction -- convolution forward (im2col rows x kernel), its data gradient
+//     (dZ x kernel^T -> col2im) and its weight gradient (im2col^T x dZ), the Dense layers and their
+//     gradients -- is ONE tiled GEMM kernel on the f32 matrix pipe (v_mfma_f32_32x32x2_f32, 64 x 64 tile
+//     per workgroup, operands staged through LDS, optional transposed operands, split over the
+//     contraction with a fixed-order reduction: no float atomics anywhere);
+//   * BatchNormalization in training mode: per-channel batch statistics by two-stage column reductions,
+//     moving statistics updated with momentum 0.99; its backward needs two more column sums;
+//   * sigmoid, shortcut add, max / average pooling and their gradients are elementwise / gather kernels;
+//   * Adagrad (Keras 2.2: a += g^2, p -= lr g / (sqrt(a) + eps)) is one elementwise kernel per tensor.
+// A small tape (list of ops over numbered tensors) is built from the topology descriptor once; a step
+// walks it forwards, then backwards accumulating gradients per tensor (the shortcut source receives two).
+#include "amt_common.h"
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+typedef float tf32x16 __attribute__((ext_vector_type(16)));
+#define TR_BN_EPS 1e-3f
+#define TR_BN_MOMENTUM 0.99f
+#define TG_TM 64
+#define TG_TN 64
+#define TG_KC 16
+
+// ---- GEMM: C[M][N] = sum_k A(m,k) B(k,n) (+ bias[n]); A stored [M][lda] (or [K][lda] when TA),
+//      B stored [K][ldb] (or [N][ldb] when TB).  gridDim.z slices of the contraction write partial
+//      tiles to `part` ([z][M][N]); splitk_reduce_kernel adds them in z order.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ B, int ldb,
+                                                     float *__restrict__ C, int ldc, int M, int N, int K,
+                                                     int kslice, const float *__restrict__ bias,
+                                                     float *__restrict__ part) {
+    __shared__ float As[TG_TM][TG_KC + 1];
+    __shared__ float Bs[TG_KC][TG_TN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m0 = blockIdx.y * TG_TM, n0 = blockIdx.x * TG_TN;
+    const int kbeg = blockIdx.z * kslice, kend = min(K, kbeg + kslice);
+    const int mi = wid >> 1, ni = wid & 1;
+    tf32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += TG_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (TG_TM * TG_KC) / 256; ++i) {
+            const int idx = tid + i * 256;
+            int r, c;
+            if (TA) { c = idx / TG_TM; r = idx - c * TG_TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
+            const int m = m0 + r, k = k0 + c;
+            float v = 0.f;
+            if (m < M && k < kend) v = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+            As[r][c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < (TG_KC * TG_TN) / 256; ++i) {
+            const int idx = tid + i * 256;
+            int c, j;
+            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TG_TN; j = idx - c * TG_TN; }
+            const int k = k0 + c, n = n0 + j;
+            float v = 0.f;
+            if (n < N && k < kend) v = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+            Bs[c][j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TG_KC; kk += 2) {
+            const float a = As[mi * 32 + (lane & 31)][kk + (lane >> 5)];
+            const float b = Bs[kk + (lane >> 5)][ni * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int n = n0 + ni * 32 + (lane & 31);
+    if (n >= N) return;
+    const float bv = (bias && !part) ? bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        if (part) part[((size_t)blockIdx.z * M + m) * N + n] = acc[e];
+        else C[(size_t)m * ldc + n] = acc[e] + bv;
+    }
+}
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, int Z, float *__restrict__ C, int ldc,
+                                     int M, int N, const float *__restrict__ bias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float v = part[i];
+    for (int z = 1; z < Z; ++z) v += part[(size_t)z * M * N + i];
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    C[(size_t)m * ldc + n] = v + (bias ? bias[n] : 0.f);
+}
+
+// ---- im2col / col2im (Keras "same" padding: before = (k-1)/2, the rest after) -------------------
+__global__ void im2col_kernel(const float *__restrict__ x, size_t x_stride, int B, int H, int W, int C, int KH,
+                              int KW, float *__restrict__ col) {
+    const size_t K = (size_t)KH * KW * C;
+    const size_t total = (size_t)B * H * W * K;
+    const int pt = (KH - 1) / 2, pl = (KW - 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pos = i / K;
+        const int kk = (int)(i - pos * K);
+        const int ci = kk % C, tap = kk / C, dx = tap % KW, dy = tap / KW;
+        const int w = (int)(pos % W), h = (int)((pos / W) % H), b = (int)(pos / ((size_t)W * H));
+        const int hh = h + dy - pt, ww = w + dx - pl;
+        col[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[(size_t)b * x_stride + ((size_t)hh * W + ww) * C + ci] : 0.f;
+    }
+}
+// dX[b][h][w][ci] = sum over taps of dcol[(b, h - dy + pt, w - dx + pl)][(dy, dx, ci)]   (gather: no atomics)
+__global__ void col2im_kernel(const float *__restrict__ dcol, int B, int H, int W, int C, int KH, int KW,
+                              float *__restrict__ dx_) {
+    const size_t total = (size_t)B * H * W * C;
+    const size_t K = (size_t)KH * KW * C;
+    const int pt = (KH - 1) / 2, pl = (KW - 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % C);
+        const size_t pos = i / C;
+        const int w = (int)(pos % W), h = (int)((pos / W) % H), b = (int)(pos / ((size_t)W * H));
+        float s = 0.f;
+        for (int dy = 0; dy < KH; ++dy) {
+            const int ho = h - dy + pt;
+            if (ho < 0 || ho >= H) continue;
+            for (int dx = 0; dx < KW; ++dx) {
+                const int wo = w - dx + pl;
+                if (wo < 0 || wo >= W) continue;
+                s += dcol[(((size_t)b * H + ho) * W + wo) * K + ((size_t)dy * KW + dx) * C + ci];
+            }
+        }
+        dx_[i] = s;
+    }
+}
+
+// ---- column reductions over a [M][C] matrix: two stages, fixed order ---------------------------------
+// mode 0: sum x;  1: sum (x - mu[c])^2;  2: (sum dy, sum dy * zhat) with zhat = (z - mu) * inv
+#define CR_SPLIT 64
+__global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict__ x, const float *__restrict__ z,
+                                                         const float *__restrict__ mu, const float *__restrict__ inv,
+                                                         size_t M, int C, int mode, float *__restrict__ part0,
+                                                         float *__restrict__ part1) {
+    // block = 8 row-lanes x 32 channels; blockIdx.x = channel block, blockIdx.y = row split
+    __shared__ float red0[8][33], red1[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const size_t rows = (M + CR_SPLIT - 1) / CR_SPLIT;
+    const size_t r0 = (size_t)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float m = (mode >= 1 && mu) ? mu[c] : 0.f, iv = mode == 2 ? inv[c] : 0.f;
+        for (size_t r = r0 + rl; r < r1; r += 8) {
+            const float v = x[r * C + c];
+            if (mode == 0) s0 += v;
+            else if (mode == 1) { const float d = v - m; s0 += d * d; }
+            else { s0 += v; s1 += v * ((z[r * C + c] - m) * iv); }
+        }
+    }
+    red0[rl][cl] = s0; red1[rl][cl] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < 8; ++i) { a += red0[i][cl]; b += red1[i][cl]; }
+        part0[(size_t)blockIdx.y * C + c] = a;
+        if (mode == 2) part1[(size_t)blockIdx.y * C + c] = b;
+    }
+}
+// mode 0 -> out0 = sum / M (mean);  mode 1 -> out0 = var = sum / M, out1 = 1/sqrt(var + eps);
+// mode 2 -> out0 = sum dy, out1 = sum dy zhat;  mode 3 -> out0 = plain sum
+__global__ void colreduce_final_kernel(const float *__restrict__ part0, const float *__restrict__ part1, int C,
+                                       float invM, int mode, float *__restrict__ out0, float *__restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < CR_SPLIT; ++s) { a += part0[(size_t)s * C + c]; if (mode == 2) b += part1[(size_t)s * C + c]; }
+    if (mode == 0) out0[c] = a * invM;
+    else if (mode == 1) { const float v = a * invM; out0[c] = v; out1[c] = 1.0f / sqrtf(v + TR_BN_EPS); }
+    else if (mode == 2) { out0[c] = a; out1[c] = b; }
+    else out0[c] = a;
+}
+
+// ---- elementwise ----------------------------------------------------------------------------------
+__global__ void bn_apply_kernel(const float *__restrict__ z, const float *__restrict__ mu, const float *__restrict__ inv,
+                                const float *__restrict__ gamma, const float *__restrict__ beta, size_t n, int C,
+                                float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        y[i] = (z[i] - mu[c]) * inv[c] * gamma[c] + beta[c];
+    }
+}
+__global__ void bn_backward_kernel(const float *dy /* may alias dz */, const float *__restrict__ z, const float *__restrict__ mu,
+                                   const float *__restrict__ inv, const float *__restrict__ gamma,
+                                   const float *__restrict__ sdy, const float *__restrict__ sdyz, float invM, size_t n,
+                                   int C, int training, float *dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float zh = (z[i] - mu[c]) * inv[c];
+        dz[i] = training ? gamma[c] * inv[c] * (dy[i] - sdy[c] * invM - zh * (sdyz[c] * invM)) : gamma[c] * inv[c] * dy[i];
+    }
+}
+__global__ void moving_update_kernel(float *__restrict__ mm, float *__restrict__ mv, const float *__restrict__ mu,
+                                     const float *__restrict__ var, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mm[c] = TR_BN_MOMENTUM * mm[c] + (1.0f - TR_BN_MOMENTUM) * mu[c];
+    mv[c] = TR_BN_MOMENTUM * mv[c] + (1.0f - TR_BN_MOMENTUM) * var[c];
+}
+__global__ void inv_from_var_kernel(const float *__restrict__ var, int C, float *__restrict__ inv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) inv[c] = 1.0f / sqrtf(var[c] + TR_BN_EPS);
+}
+__global__ void sigmoid_fwd_kernel(const float *__restrict__ x, size_t n, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float *dy, const float *__restrict__ a, size_t n, float *dx) {   // dy may alias dx
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * a[i] * (1.0f - a[i]);
+}
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a[i] + b[i];
+}
+__global__ void accumulate_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+// pooling (valid, stride = pool); out rows may be written with a row pitch (flatten into the dense input)
+__global__ void pool_fwd_kernel(const float *__restrict__ x, int B, int H, int W, int C, int PH, int PW, int is_max,
+                                float *__restrict__ y, size_t y_stride) {
+    const int HO = H / PH, WO = W / PW;
+    const size_t total = (size_t)B * HO * WO * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int wo = (int)(r % WO); r /= WO;
+        const int ho = (int)(r % HO);
+        const int b = (int)(r / HO);
+        float m = is_max ? -INFINITY : 0.f;
+        for (int dy = 0; dy < PH; ++dy)
+            for (int dx = 0; dx < PW; ++dx) {
+                const float v = x[(((size_t)b * H + ho * PH + dy) * W + wo * PW + dx) * C + c];
+                m = is_max ? fmaxf(m, v) : m + v;
+            }
+        if (!is_max) m /= (float)(PH * PW);
+        y[(size_t)b * y_stride + ((size_t)ho * WO + wo) * C + c] = m;
+    }
+}
+// gradient of the pooling: max routes to the FIRST maximum in (dy, dx) order; the part of x the valid
+// pooling never read gets zero
+__global__ void pool_bwd_kernel(const float *__restrict__ dy_, size_t dy_stride, const float *__restrict__ x, int B, int H,
+                                int W, int C, int PH, int PW, int is_max, float *__restrict__ dx_) {
+    const int HO = H / PH, WO = W / PW;
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const int ho = h / PH, wo = w / PW;
+        float g = 0.f;
+        if (ho < HO && wo < WO) {
+            const float d = dy_[(size_t)b * dy_stride + ((size_t)ho * WO + wo) * C + c];
+            if (!is_max) g = d / (float)(PH * PW);
+            else {
+                int best = 0; float bv = -INFINITY;
+                for (int dy = 0; dy < PH; ++dy)
+                    for (int dx = 0; dx < PW; ++dx) {
+                        const float v = x[(((size_t)b * H + ho * PH + dy) * W + wo * PW + dx) * C + c];
+                        if (v > bv) { bv = v; best = dy * PW + dx; }
+                    }
+                g = ((h - ho * PH) * PW + (w - wo * PW)) == best ? d : 0.f;
+            }
+        }
+        dx_[i] = g;
+    }
+}
+__global__ void copy_rows_kernel(const float *__restrict__ src, size_t src_stride, float *__restrict__ dst,
+                                 size_t dst_stride, int B, size_t n) {
+    const size_t total = (size_t)B * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / n, j = i - b * n;
+        dst[b * dst_stride + j] = src[b * src_stride + j];
+    }
+}
+// loss + gradient wrt the last Dense's output.  K == 1: pred = sigmoid(z), loss = mean (pred - y)^2 (Keras
+// mean_squared_error on the activation-scale target); K > 1: softmax + sparse categorical cross-entropy.
+__global__ void loss_kernel(const float *__restrict__ z, const float *__restrict__ y, int B, int K, float *__restrict__ pred,
+                            float *__restrict__ dz, float *__restrict__ loss_rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *l = z + (size_t)b * K;
+    if (K == 1) {
+        const float p = 1.0f / (1.0f + expf(-l[0]));
+        const float d = p - y[b];
+        pred[b] = p;
+        loss_rows[b] = d * d;
+        dz[b] = 2.0f * d / (float)B * p * (1.0f - p);
+    } else {
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, l[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(l[k] - m);
+        int yi = (int)y[b];
+        yi = yi < 0 ? 0 : (yi >= K ? K - 1 : yi);
+        for (int k = 0; k < K; ++k) {
+            const float p = expf(l[k] - m) / s;
+            pred[(size_t)b * K + k] = p;
+            dz[(size_t)b * K + k] = (p - (k == yi ? 1.0f : 0.0f)) / (float)B;
+        }
+        loss_rows[b] = -(l[yi] - m - logf(s));
+    }
+}
+__global__ void adagrad_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ acc, size_t n,
+                               float lr, float eps) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float a = acc[i] + gi * gi;
+        acc[i] = a;
+        p[i] = p[i] - lr * gi / (sqrtf(a) + eps);
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+namespace {
+
+struct Param { float *w = nullptr, *g = nullptr, *acc = nullptr; size_t n = 0; bool trainable = true; };
+
+enum OpKind { OP_CONV, OP_BN, OP_SIGMOID, OP_ADD, OP_POOL, OP_FLATTEN, OP_DENSE };
+struct Op {
+    OpKind kind;
+    int in0 = -1, in1 = -1, out = -1;             // tensor ids
+    int H = 0, W = 0, Cin = 0, Cout = 0, kh = 1, kw = 1;    // conv / dense (H = W = 1) / pool (kh, kw = pool)
+    int is_max = 0;
+    int p0 = -1, p1 = -1, p2 = -1, p3 = -1;       // params: conv/dense (kernel, bias); bn (gamma, beta, mean, var)
+    int flat_off = 0;                              // OP_FLATTEN: column offset in the dense input
+    float *bmu = nullptr, *binv = nullptr, *bvar = nullptr;      // BN batch statistics of the last forward
+};
+struct Tensor { int H, W, C; bool flat = false; float *v = nullptr, *g = nullptr; bool g_set = false; };
+
+static unsigned grid1(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 65535); }
+
+}  // namespace
+
+struct amt_trainer {
+    amt_rdcnn_desc d;
+    std::vector<Param> params;                    // canonical order (rdcnn.py pack_weights)
+    std::vector<Op> ops;
+    std::vector<Tensor> tensors;
+    std::vector<int> inputs;                      // tensor id of each tower's input
+    int t_flat = -1, t_logits = -1;
+    int flat = 0, capB = 0;
+    float lr = 0.01f, eps = 1e-7f;
+    float *col = nullptr, *part = nullptr, *red0 = nullptr, *red1 = nullptr, *stat0 = nullptr, *stat1 = nullptr;
+    float *pred = nullptr, *loss_rows = nullptr, *dlogits = nullptr;
+    size_t col_cap = 0, part_cap = 0;
+    std::vector<float *> allocs;
+};
+
+namespace {
+
+int talloc(amt_trainer *t, size_t n, float **out, bool zero = false) {
+    float *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) return AMT_E_NOMEM;
+    if (zero && hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) return AMT_E_HIP;
+    t->allocs.push_back(p);
+    *out = p;
+    return AMT_OK;
+}
+
+int add_param(amt_trainer *t, const float *&cur, size_t n, bool trainable) {
+    Param p;
+    p.n = n; p.trainable = trainable;
+    int rc = talloc(t, n, &p.w);
+    if (rc != AMT_OK) return -1;
+    if (hipMemcpy(p.w, cur, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    cur += n;
+    if (trainable) {
+        if (talloc(t, n, &p.g, true) != AMT_OK || talloc(t, n, &p.acc, true) != AMT_OK) return -1;
+    }
+    t->params.push_back(p);
+    return (int)t->params.size() - 1;
+}
+
+int new_tensor(amt_trainer *t, int H, int W, int C, bool flat = false) {
+    Tensor x; x.H = H; x.W = W; x.C = C; x.flat = flat;
+    t->tensors.push_back(x);
+    return (int)t->tensors.size() - 1;
+}
+
+// GEMM dispatch with split over the contraction when the output grid is small
+int gemm(amt_trainer *t, bool TA, bool TB, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+         int M, int N, int K, const float *bias, hipStream_t st) {
+    const int gx = (N + TG_TN - 1) / TG_TN, gy = (M + TG_TM - 1) / TG_TM;
+    int Z = 1;
+    const long tiles = (long)gx * gy;
+    if (tiles < 512 && K > 4 * TG_KC) Z = (int)std::min<long>((512 + tiles - 1) / tiles, (K + 4 * TG_KC - 1) / (4 * TG_KC));
+    Z = std::min(Z, 256);
+    int kslice = ((K + Z - 1) / Z + TG_KC - 1) / TG_KC * TG_KC;
+    Z = (K + kslice - 1) / kslice;
+    float *part = nullptr;
+    if (Z > 1) {
+        const size_t need = (size_t)Z * M * N;
+        if (need > t->part_cap) {
+            if (talloc(t, need, &t->part) != AMT_OK) return AMT_E_NOMEM;
+            t->part_cap = need;
+        }
+        part = t->part;
+    }
+    dim3 grid(gx, gy, Z);
+#define TG_LAUNCH(ta, tb) tgemm_kernel<ta, tb><<<grid, 256, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kslice, bias, part)
+    if (TA && TB) return AMT_E_UNSUPPORTED;
+    if (TA) TG_LAUNCH(true, false); else if (TB) TG_LAUNCH(false, true); else TG_LAUNCH(false, false);
+#undef TG_LAUNCH
+    if (Z > 1) splitk_reduce_kernel<<<grid1((size_t)M * N), 256, 0, st>>>(part, Z, C, ldc, M, N, bias);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int colreduce(amt_trainer *t, const float *x, const float *z, const float *mu, const float *inv, size_t M, int C, int mode,
+              float *out0, float *out1, hipStream_t st) {
+    colreduce_kernel<<<dim3((C + 31) / 32, CR_SPLIT), 256, 0, st>>>(x, z, mu, inv, M, C, mode, t->red0, t->red1);
+    colreduce_final_kernel<<<(C + 63) / 64, 64, 0, st>>>(t->red0, t->red1, C, 1.0f / (float)M, mode, out0, out1);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amt_trainer_destroy(amt_trainer *t) {
+    if (!t) return AMT_OK;
+    for (float *p : t->allocs) (void)hipFree(p);
+    delete t;
+    return AMT_OK;
+}
+
+int amt_trainer_create(amt_trainer **out, const amt_rdcnn_desc *desc, const float *wh, size_t n_floats, float lr,
+                       float epsilon) {
+    if (!out || !desc || !wh) return AMT_E_INVALID;
+    if ((size_t)amt_rdcnn_param_count(desc) != n_floats || n_floats == 0) return AMT_E_SHAPE;
+    const amt_rdcnn_desc &d = *desc;
+    amt_trainer *t = new amt_trainer();
+    t->d = d;
+    if (lr > 0.f) t->lr = lr;
+    if (epsilon > 0.f) t->eps = epsilon;
+    const float *cur = wh;
+#define TR_P(n, tr) add_param(t, cur, (size_t)(n), tr)
+#define TR_FAIL() do { amt_trainer_destroy(t); return AMT_E_NOMEM; } while (0)
+    auto bn_op = [&](int in, int C) -> int {
+        Op o; o.kind = OP_BN; o.in0 = in; o.Cout = C;
+        o.p0 = TR_P(C, true); o.p1 = TR_P(C, true); o.p2 = TR_P(C, false); o.p3 = TR_P(C, false);
+        if (o.p0 < 0 || o.p1 < 0 || o.p2 < 0 || o.p3 < 0) return -1;
+        const Tensor &x = t->tensors[in];
+        o.out = new_tensor(t, x.H, x.W, C);
+        if (talloc(t, C, &o.bmu) != AMT_OK || talloc(t, C, &o.binv) != AMT_OK || talloc(t, C, &o.bvar) != AMT_OK) return -1;
+        t->ops.push_back(o);
+        return o.out;
+    };
+    std::vector<std::pair<int, int>> tails;               // (tensor, flat offset)
+    int flat = 0;
+    for (int tw = 0; tw < d.n_towers; ++tw) {
+        int H = d.in_h[tw], W = d.in_w[tw], C = 1, fo = 32;
+        int cur_t = new_tensor(t, H, W, 1);
+        t->inputs.push_back(cur_t);
+        int p0 = cur_t;
+        for (int i = 1; i <= d.conv_layers; ++i) {
+            Op c; c.kind = OP_CONV; c.in0 = cur_t; c.H = H; c.W = W; c.Cin = C; c.Cout = fo; c.kh = d.kh[tw]; c.kw = d.kw[tw];
+            c.p0 = TR_P((size_t)c.kh * c.kw * C * fo, true); c.p1 = TR_P(fo, true);
+            if (c.p0 < 0 || c.p1 < 0) TR_FAIL();
+            c.out = new_tensor(t, H, W, fo);
+            t->ops.push_back(c);
+            int z = bn_op(c.out, fo);
+            if (z < 0) TR_FAIL();
+            Op s; s.kind = OP_SIGMOID; s.in0 = z; s.out = new_tensor(t, H, W, fo);
+            t->ops.push_back(s);
+            cur_t = s.out; C = fo;
+            if (d.residual_frequency > 0 && i % d.residual_frequency == 0) {
+                int a = p0;
+                const Tensor src = t->tensors[p0];
+                if (!(src.H == H && src.W == W && src.C == C)) {
+                    if (src.C != C) {
+                        Op pc; pc.kind = OP_CONV; pc.in0 = a; pc.H = src.H; pc.W = src.W; pc.Cin = src.C; pc.Cout = C; pc.kh = 1; pc.kw = 1;
+                        pc.p0 = TR_P((size_t)src.C * C, true); pc.p1 = TR_P(C, true);
+                        if (pc.p0 < 0 || pc.p1 < 0) TR_FAIL();
+                        pc.out = new_tensor(t, src.H, src.W, C);
+                        t->ops.push_back(pc);
+                        a = pc.out;
+                    }
+                    if (src.H != H || src.W != W) {
+                        Op ap; ap.kind = OP_POOL; ap.in0 = a; ap.is_max = 0; ap.kh = src.H / H; ap.kw = src.W / W;
+                        ap.H = src.H; ap.W = src.W; ap.Cin = C;
+                        if (src.H / ap.kh != H || src.W / ap.kw != W) { amt_trainer_destroy(t); return AMT_E_UNSUPPORTED; }
+                        ap.out = new_tensor(t, H, W, C);
+                        t->ops.push_back(ap);
+                        a = ap.out;
+                    }
+                    a = bn_op(a, C);
+                    if (a < 0) TR_FAIL();
+                }
+                Op ad; ad.kind = OP_ADD; ad.in0 = a; ad.in1 = cur_t; ad.out = new_tensor(t, H, W, C);
+                t->ops.push_back(ad);
+                cur_t = bn_op(ad.out, C);
+                if (cur_t < 0) TR_FAIL();
+                p0 = cur_t;
+            }
+            if (d.pool_layer_frequency > 0 && i % d.pool_layer_frequency == 0) {
+                Op mp; mp.kind = OP_POOL; mp.in0 = cur_t; mp.is_max = 1; mp.kh = d.pool_h[tw]; mp.kw = d.pool_w[tw];
+                mp.H = H; mp.W = W; mp.Cin = C;
+                H /= mp.kh; W /= mp.kw;
+                if (H < 1 || W < 1) { amt_trainer_destroy(t); return AMT_E_UNSUPPORTED; }
+                mp.out = new_tensor(t, H, W, C);
+                t->ops.push_back(mp);
+                cur_t = mp.out;
+            }
+            if (d.feature_expand_frequency > 0 && i % d.feature_expand_frequency == 0) fo *= 2;
+        }
+        tails.push_back({cur_t, flat});
+        flat += H * W * C;
+    }
+    t->flat = flat;
+    t->t_flat = new_tensor(t, 1, 1, flat, true);
+    for (auto &tl : tails) {
+        Op f; f.kind = OP_FLATTEN; f.in0 = tl.first; f.out = t->t_flat; f.flat_off = tl.second;
+        t->ops.push_back(f);
+    }
+    {
+        Op d1; d1.kind = OP_DENSE; d1.in0 = t->t_flat; d1.Cin = flat; d1.Cout = d.dense_units;
+        d1.p0 = TR_P((size_t)flat * d.dense_units, true); d1.p1 = TR_P(d.dense_units, true);
+        if (d1.p0 < 0 || d1.p1 < 0) TR_FAIL();
+        d1.out = new_tensor(t, 1, 1, d.dense_units, true);
+        t->ops.push_back(d1);
+        Op s; s.kind = OP_SIGMOID; s.in0 = d1.out; s.out = new_tensor(t, 1, 1, d.dense_units, true);
+        t->ops.push_back(s);
+        Op d2; d2.kind = OP_DENSE; d2.in0 = s.out; d2.Cin = d.dense_units; d2.Cout = d.output_classes;
+        d2.p0 = TR_P((size_t)d.dense_units * d.output_classes, true); d2.p1 = TR_P(d.output_classes, true);
+        if (d2.p0 < 0 || d2.p1 < 0) TR_FAIL();
+        d2.out = new_tensor(t, 1, 1, d.output_classes, true);
+        t->ops.push_back(d2);
+        t->t_logits = d2.out;
+    }
+#undef TR_P
+#undef TR_FAIL
+    if ((size_t)(cur - wh) != n_floats) { amt_trainer_destroy(t); return AMT_E_SHAPE; }
+    int maxC = 1;
+    for (const Tensor &x : t->tensors) maxC = std::max(maxC, x.C);
+    if (talloc(t, (size_t)CR_SPLIT * maxC, &t->red0) != AMT_OK || talloc(t, (size_t)CR_SPLIT * maxC, &t->red1) != AMT_OK ||
+        talloc(t, maxC, &t->stat0) != AMT_OK || talloc(t, maxC, &t->stat1) != AMT_OK) {
+        amt_trainer_destroy(t); return AMT_E_NOMEM;
+    }
+    *out = t;
+    return AMT_OK;
+}
+
+static int ensure_batch(amt_trainer *t, int B) {
+    if (B <= t->capB) return AMT_OK;
+    // (re)allocate activations and gradients for B windows; earlier, smaller buffers stay owned until destroy
+    size_t col_need = 0;
+    for (Tensor &x : t->tensors) {
+        const size_t n = (size_t)B * x.H * x.W * x.C;
+        if (talloc(t, n, &x.v) != AMT_OK || talloc(t, n, &x.g) != AMT_OK) return AMT_E_NOMEM;
+    }
+    for (const Op &o : t->ops)
+        if (o.kind == OP_CONV) col_need = std::max(col_need, (size_t)B * o.H * o.W * o.kh * o.kw * o.Cin);
+    if (talloc(t, col_need, &t->col) != AMT_OK) return AMT_E_NOMEM;
+    t->col_cap = col_need;
+    const int K = t->d.output_classes;
+    if (talloc(t, (size_t)B * K, &t->pred) != AMT_OK || talloc(t, B, &t->loss_rows) != AMT_OK ||
+        talloc(t, (size_t)B * K, &t->dlogits) != AMT_OK)
+        return AMT_E_NOMEM;
+    t->capB = B;
+    return AMT_OK;
+}
+
+// gradient arriving at tensor `id`: first arrival assigns, later ones add
+static int give_grad(amt_trainer *t, int id, const float *src, size_t n, hipStream_t st) {
+    Tensor &x = t->tensors[id];
+    if (!x.g_set) {
+        if (x.g != src) AMT_HIP_CHECK(hipMemcpyAsync(x.g, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        x.g_set = true;
+    } else {
+        accumulate_kernel<<<grid1(n), 256, 0, st>>>(x.g, src, n);
+    }
+    return AMT_OK;
+}
+
+int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int B, int update, float *loss_host,
+                     float *pred_out, void *stream) {
+    if (!t || !x || !y || B <= 0) return AMT_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_batch(t, B);
+    if (rc != AMT_OK) return rc;
+    const int training = update ? 1 : 0;
+    const int K = t->d.output_classes;
+    for (size_t i = 0; i < t->inputs.size(); ++i) {
+        if (!x[i]) return AMT_E_INVALID;
+        Tensor &in = t->tensors[t->inputs[i]];
+        AMT_HIP_CHECK(hipMemcpyAsync(in.v, x[i], (size_t)B * in.H * in.W * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    // ---------------- forward ----------------------------------------------------------------
+    for (Op &o : t->ops) {
+        Tensor &in = t->tensors[o.in0];
+        Tensor &out = t->tensors[o.out];
+        const size_t nin = (size_t)B * in.H * in.W * in.C, nout = (size_t)B * out.H * out.W * out.C;
+        switch (o.kind) {
+        case OP_CONV: {
+            const size_t M = (size_t)B * o.H * o.W;
+            const int Kc = o.kh * o.kw * o.Cin;
+            const float *A = in.v;
+            if (!(o.kh == 1 && o.kw == 1)) {
+                im2col_kernel<<<grid1(M * Kc), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
+                A = t->col;
+            }
+            rc = gemm(t, false, false, A, Kc, t->params[o.p0].w, o.Cout, out.v, o.Cout, (int)M, o.Cout, Kc, t->params[o.p1].w, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_BN: {
+            const size_t M = nin / o.Cout;
+            if (training) {
+                rc = colreduce(t, in.v, nullptr, nullptr, nullptr, M, o.Cout, 0, o.bmu, nullptr, st);
+                if (rc == AMT_OK) rc = colreduce(t, in.v, nullptr, o.bmu, nullptr, M, o.Cout, 1, o.bvar, o.binv, st);
+                if (rc != AMT_OK) return rc;
+            } else {
+                AMT_HIP_CHECK(hipMemcpyAsync(o.bmu, t->params[o.p2].w, o.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+                inv_from_var_kernel<<<(o.Cout + 63) / 64, 64, 0, st>>>(t->params[o.p3].w, o.Cout, o.binv);
+            }
+            bn_apply_kernel<<<grid1(nin), 256, 0, st>>>(in.v, o.bmu, o.binv, t->params[o.p0].w, t->params[o.p1].w, nin, o.Cout, out.v);
+            break;
+        }
+        case OP_SIGMOID:
+            sigmoid_fwd_kernel<<<grid1(nin), 256, 0, st>>>(in.v, nin, out.v);
+            break;
+        case OP_ADD:
+            add_kernel<<<grid1(nin), 256, 0, st>>>(in.v, t->tensors[o.in1].v, nin, out.v);
+            break;
+        case OP_POOL:
+            pool_fwd_kernel<<<grid1(nout), 256, 0, st>>>(in.v, B, o.H, o.W, o.Cin, o.kh, o.kw, o.is_max, out.v,
+                                                          (size_t)out.H * out.W * out.C);
+            break;
+        case OP_FLATTEN:
+            copy_rows_kernel<<<grid1(nin), 256, 0, st>>>(in.v, (size_t)in.H * in.W * in.C, out.v + o.flat_off, (size_t)t->flat,
+                                                          B, (size_t)in.H * in.W * in.C);
+            break;
+        case OP_DENSE:
+            rc = gemm(t, false, false, in.v, o.Cin, t->params[o.p0].w, o.Cout, out.v, o.Cout, B, o.Cout, o.Cin, t->params[o.p1].w, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+    }
+    AMT_LAUNCH_CHECK();
+    // ---------------- loss --------------------------------------------------------------------
+    loss_kernel<<<(B + 63) / 64, 64, 0, st>>>(t->tensors[t->t_logits].v, y, B, K, t->pred, t->dlogits, t->loss_rows);
+    if (pred_out) AMT_HIP_CHECK(hipMemcpyAsync(pred_out, t->pred, (size_t)B * K * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (loss_host) {
+        std::vector<float> rows(B);
+        AMT_HIP_CHECK(hipMemcpyAsync(rows.data(), t->loss_rows, B * sizeof(float), hipMemcpyDeviceToHost, st));
+        AMT_HIP_CHECK(hipStreamSynchronize(st));
+        double s = 0;
+        for (float v : rows) s += v;
+        *loss_host = (float)(s / B);
+    }
+    if (!update) return AMT_OK;
+    // ---------------- backward ----------------------------------------------------------------
+    for (Tensor &x_ : t->tensors) x_.g_set = false;
+    rc = give_grad(t, t->t_logits, t->dlogits, (size_t)B * K, st);
+    if (rc != AMT_OK) return rc;
+    // scratch for gradients before they are handed to their tensor: reuse col (conv) or a tensor-sized temp
+    for (int oi = (int)t->ops.size() - 1; oi >= 0; --oi) {
+        Op &o = t->ops[oi];
+        Tensor &in = t->tensors[o.in0];
+        Tensor &out = t->tensors[o.out];
+        const size_t nin = (size_t)B * in.H * in.W * in.C;
+        if (o.kind != OP_FLATTEN && !out.g_set) continue;          // no gradient reaches this op
+        switch (o.kind) {
+        case OP_DENSE: {
+            // dW = in^T dOut, db = colsum dOut, dIn = dOut W^T
+            rc = gemm(t, true, false, in.v, o.Cin, out.g, o.Cout, t->params[o.p0].g, o.Cout, o.Cin, o.Cout, B, nullptr, st);
+            if (rc == AMT_OK) rc = colreduce(t, out.g, nullptr, nullptr, nullptr, (size_t)B, o.Cout, 3, t->params[o.p1].g, nullptr, st);
+            if (rc != AMT_OK) return rc;
+            // dIn into a temporary (the col buffer is free here), then handed over
+            if ((size_t)B * o.Cin > t->col_cap) return AMT_E_NOMEM;
+            rc = gemm(t, false, true, out.g, o.Cout, t->params[o.p0].w, o.Cout, t->col, o.Cin, B, o.Cin, o.Cout, nullptr, st);
+            if (rc == AMT_OK) rc = give_grad(t, o.in0, t->col, (size_t)B * o.Cin, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_FLATTEN: {
+            Tensor &fl = t->tensors[o.out];
+            if (!fl.g_set) break;
+            // rows of the dense input's gradient -> this tower's last activation (written straight into its grad)
+            copy_rows_kernel<<<grid1(nin), 256, 0, st>>>(fl.g + o.flat_off, (size_t)t->flat, in.g, (size_t)in.H * in.W * in.C, B,
+                                                          (size_t)in.H * in.W * in.C);
+            in.g_set = true;
+            break;
+        }
+        case OP_SIGMOID: {
+            // in place on out.g is not possible (out.g may be read again): write to in.g via give_grad path
+            sigmoid_bwd_kernel<<<grid1(nin), 256, 0, st>>>(out.g, out.v, nin, out.g);      // out.g is dead after this op
+            rc = give_grad(t, o.in0, out.g, nin, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_ADD: {
+            rc = give_grad(t, o.in0, out.g, nin, st);
+            if (rc == AMT_OK) rc = give_grad(t, o.in1, out.g, nin, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_POOL: {
+            if (nin > t->col_cap) return AMT_E_NOMEM;
+            pool_bwd_kernel<<<grid1(nin), 256, 0, st>>>(out.g, (size_t)out.H * out.W * out.C, in.v, B, o.H, o.W, o.Cin, o.kh, o.kw,
+                                                         o.is_max, t->col);
+            rc = give_grad(t, o.in0, t->col, nin, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_BN: {
+            const size_t M = nin / o.Cout;
+            // dgamma = sum dy zhat, dbeta = sum dy; dz in place of dy (out.g is dead afterwards)
+            rc = colreduce(t, out.g, in.v, o.bmu, o.binv, M, o.Cout, 2, t->params[o.p1].g, t->params[o.p0].g, st);
+            if (rc != AMT_OK) return rc;
+            bn_backward_kernel<<<grid1(nin), 256, 0, st>>>(out.g, in.v, o.bmu, o.binv, t->params[o.p0].w, t->params[o.p1].g,
+                                                            t->params[o.p0].g, 1.0f / (float)M, nin, o.Cout, 1, out.g);
+            rc = give_grad(t, o.in0, out.g, nin, st);
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        case OP_CONV: {
+            const size_t M = (size_t)B * o.H * o.W;
+            const int Kc = o.kh * o.kw * o.Cin;
+            const bool one = o.kh == 1 && o.kw == 1;
+            const float *A = in.v;
+            if (!one) {
+                im2col_kernel<<<grid1(M * Kc), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
+                A = t->col;
+            }
+            rc = gemm(t, true, false, A, Kc, out.g, o.Cout, t->params[o.p0].g, o.Cout, Kc, o.Cout, (int)M, nullptr, st);
+            if (rc == AMT_OK) rc = colreduce(t, out.g, nullptr, nullptr, nullptr, M, o.Cout, 3, t->params[o.p1].g, nullptr, st);
+            if (rc != AMT_OK) return rc;
+            const bool is_input = std::find(t->inputs.begin(), t->inputs.end(), o.in0) != t->inputs.end();
+            if (is_input) break;                                        // no gradient wrt the network input
+            // dcol = dOut W^T (into col: the im2col rows are consumed), then gathered back to the image
+            rc = gemm(t, false, true, out.g, o.Cout, t->params[o.p0].w, o.Cout, t->col, Kc, (int)M, Kc, o.Cout, nullptr, st);
+            if (rc != AMT_OK) return rc;
+            if (one) rc = give_grad(t, o.in0, t->col, nin, st);
+            else {
+                // out.v is dead in the backward pass of this op's producer side? No: keep it; use out.g as the target
+                // (dOut has been consumed by both GEMMs above) when it is large enough, else a fresh view of in.g
+                float *dst = nullptr;
+                Tensor &inT = t->tensors[o.in0];
+                if (!inT.g_set) { dst = inT.g; }
+                else if ((size_t)B * out.H * out.W * out.C >= nin) dst = out.g;
+                else return AMT_E_NOMEM;
+                col2im_kernel<<<grid1(nin), 256, 0, st>>>(t->col, B, o.H, o.W, o.Cin, o.kh, o.kw, dst);
+                rc = give_grad(t, o.in0, dst, nin, st);
+            }
+            if (rc != AMT_OK) return rc;
+            break;
+        }
+        }
+    }
+    AMT_LAUNCH_CHECK();
+    // ---------------- update -------------------------------------------------------------------
+    for (Op &o : t->ops)
+        if (o.kind == OP_BN)
+            moving_update_kernel<<<(o.Cout + 63) / 64, 64, 0, st>>>(t->params[o.p2].w, t->params[o.p3].w, o.bmu, o.bvar, o.Cout);
+    for (Param &p : t->params)
+        if (p.trainable) adagrad_kernel<<<grid1(p.n), 256, 0, st>>>(p.w, p.g, p.acc, p.n, t->lr, t->eps);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+static int copy_out(amt_trainer *t, float *host, size_t n, bool grads) {
+    if (!t || !host) return AMT_E_INVALID;
+    size_t total = 0;
+    for (const Param &p : t->params) total += p.n;
+    if (total != n) return AMT_E_SHAPE;
+    AMT_HIP_CHECK(hipDeviceSynchronize());
+    float *cur = host;
+    for (const Param &p : t->params) {
+        if (grads && !p.trainable) memset(cur, 0, p.n * sizeof(float));
+        else AMT_HIP_CHECK(hipMemcpy(cur, grads ? p.g : p.w, p.n * sizeof(float), hipMemcpyDeviceToHost));
+        cur += p.n;
+    }
+    return AMT_OK;
+}
+int amt_trainer_get_weights(amt_trainer *t, float *weights_host, size_t n_floats) { return copy_out(t, weights_host, n_floats, false); }
+int amt_trainer_get_grads(amt_trainer *t, float *grads_host, size_t n_floats) { return copy_out(t, grads_host, n_floats, true); }
+
+}  // extern "C"

@@ -281,6 +281,32 @@ int amt_rdcnn_profile(amt_rdcnn *net, int enable);
 int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *windows,
                            double *flops_per_window, int cap, int *n_rows, int reset);
 
+/* ------------------------------------------------------------------------ *
+ * RDCNN training step (replaces res_net.train / res_net.test, RDCNN.py:503-526, :559-589: Keras
+ * train_on_batch / test_on_batch of the model compiled at RDCNN.py:245-254 with Adagrad and
+ * mean_squared_error (one output) or sparse_categorical_crossentropy).
+ * ------------------------------------------------------------------------ */
+typedef struct amt_trainer amt_trainer;
+
+/* weights_host: the canonical blob of amt_rdcnn_create (trainable tensors AND the BN moving statistics).
+ * lr / epsilon <= 0 select the Keras 2.2 defaults of Adagrad (0.01, 1e-7); accumulators start at zero. */
+int amt_trainer_create(amt_trainer **trainer, const amt_rdcnn_desc *desc, const float *weights_host,
+                       size_t n_floats, float lr, float epsilon);
+int amt_trainer_destroy(amt_trainer *trainer);
+/* One batch.  x[t]: device [B][in_h][in_w] per tower; y: device [B] f32 -- the class index (softmax heads)
+ * or the target ALREADY scaled to the activation range (RDCNN.py:304-306, :513-514).
+ * update != 0: train_on_batch -- BatchNormalization with batch statistics (moving statistics updated with
+ *   momentum 0.99), backward pass, Adagrad step.
+ * update == 0: test_on_batch -- inference-mode forward and the loss only.
+ * loss_host (may be NULL): the batch loss; reading it synchronises the stream.
+ * pred (may be NULL): device [B][output_classes], sigmoid activation / softmax probabilities. */
+int amt_trainer_step(amt_trainer *trainer, const float *const *x, const float *y, int B, int update,
+                     float *loss_host, float *pred, void *stream);
+/* canonical blob back to the host (synchronises): current weights / the gradients of the last step
+ * (zeros for the BN moving statistics) */
+int amt_trainer_get_weights(amt_trainer *trainer, float *weights_host, size_t n_floats);
+int amt_trainer_get_grads(amt_trainer *trainer, float *grads_host, size_t n_floats);
+
 #ifdef __cplusplus
 }
 #endif

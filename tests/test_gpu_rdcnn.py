@@ -278,8 +278,15 @@ def test_classify_contract(env):
     with pytest.raises(ValueError) as e:
         h.classify([np.zeros((35, 8), np.float32)])
     assert 'Invalid Input shape. Expected: (36, 8) . Got: (35, 8)' in str(e.value)
-    with pytest.raises(NotImplementedError):
-        h.classify(spec, [1, 2, 3, 4])
+    # with gold: one training step on the batch (velocity_classifier.py:48-55); with test_phase: no update
+    w0 = {k: v.copy() for k, v in h.weights.items()}
+    yt = h.classify(spec, [40, 50, 60, 70], test_phase=True)
+    assert yt.shape == (4, 1) and np.array_equal(yt, y) and len(h.metrics_test) == 1
+    ytr = h.classify(spec, [40, 50, 60, 70])
+    assert ytr.shape == (4, 1) and len(h.metrics_train) == 1 and h.current_batch == 2
+    y2 = h.classify(spec)                                   # predict pulls the trained weights back
+    assert not np.array_equal(y2, y)
+    assert any(not np.array_equal(h.weights[k], w0[k]) for k in w0)
 
 
 def test_cqt_slices(env):

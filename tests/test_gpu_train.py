@@ -1,0 +1,103 @@
+"""GPU parity of the training step (amt_trainer_step: training-mode BN, backward, Adagrad; res_net.train /
+.test, RDCNN.py:503-589) against the numpy training oracle (oracle/train.py, itself pinned to PyTorch
+autograd in tests/test_oracle_train.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_train import CASES      # noqa: E402  (the shallow topologies: every layer kind)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    from amt_saga import rdcnn, heads, hyperparams
+    from oracle import train as otr, rdcnn as orc
+    return dict(torch=torch, rdcnn=rdcnn, heads=heads, hp=hyperparams, otr=otr, orc=orc)
+
+
+def _batch(cfg, B, seed):
+    rng = np.random.default_rng(seed)
+    xs = [(rng.random((B,) + tuple(s[:2]) + (1,)) ** 2).astype(np.float32) for s in cfg['input_shapes']]
+    if cfg['output_classes'] > 1:
+        y = rng.integers(0, cfg['output_classes'], B).astype(np.float64)
+    else:
+        lo, hi = cfg['output_range']
+        y = rng.uniform(lo, hi, B)
+    return xs, y
+
+
+def _to_act(net, y):
+    return net._scale_output_to_activation(y) if net.output_classes == 1 else y
+
+
+def _compare_step(env, net, xs, y, w_before, acc, tag):
+    """One train() on the device vs one oracle train_on_batch from the same state; returns the oracle's state."""
+    pred = net.train(xs if len(xs) > 1 else xs[0], y)
+    loss = net.metrics_train[-1][0]
+    grads = net.gradients()
+    o_loss, o_pred, g, stats = env['otr'].forward_backward(w_before, net.cfg, xs, _to_act(net, y), np.float32)
+    o_loss2, _, w_after, acc2 = env['otr'].train_on_batch(w_before, net.cfg, xs, _to_act(net, y), acc=acc, dtype=np.float32)
+    assert abs(loss - o_loss) <= 2e-5 * max(abs(o_loss), 1e-3), (tag, loss, o_loss)
+    o_out = net._scale_activation_to_output(o_pred) if net.output_classes == 1 else o_pred
+    assert np.abs(pred - o_out).max() <= 1e-4 * max(np.abs(o_out).max(), 1e-6), tag
+    gmax = max(np.abs(v).max() for v in g.values())
+    for k, gk in g.items():
+        err = np.abs(grads[k] - gk).max()
+        assert err <= 3e-4 * np.abs(gk).max() + 2e-6 * gmax, (tag, k, err, np.abs(gk).max(), gmax)
+    net._sync_from_trainer()
+    for k, gk in g.items():
+        if np.abs(gk).max() < 1e-4 * gmax:
+            continue                      # structurally zero gradient (a bias in front of a training-mode BN): Adagrad
+        #                                   divides noise by noise there, in Keras as here
+        big = np.abs(gk) > 1e-3 * np.abs(gk).max()          # elements whose sign and size are not rounding noise
+        assert np.abs(net.weights[k] - w_after[k])[big].max() <= 2e-4, (tag, k)
+    for p_ in stats:
+        for leaf in ('mean', 'var'):
+            a, b = net.weights[p_ + '/' + leaf], w_after[p_ + '/' + leaf]
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-3), (tag, p_, leaf)
+    return w_after, acc2
+
+
+@pytest.mark.parametrize('case', range(len(CASES)))
+def test_train_step_vs_oracle(env, case):
+    net = env['rdcnn'].res_net(weight_seed=31 + case, calibrated=False, **CASES[case])
+    xs, y = _batch(net.cfg, 6, case)
+    w0 = {k: v.copy() for k, v in net.weights.items()}
+    w1, acc = _compare_step(env, net, xs, y, w0, None, 'step1')
+    # second step from the device's own state (accumulators carry over); the oracle restarts from the device's weights
+    # so that rounding-level differences of step 1 do not compound into the comparison
+    dev_w1 = {k: v.copy() for k, v in net.weights.items()}
+    xs2, y2 = _batch(net.cfg, 6, case + 100)
+    _compare_step(env, net, xs2, y2, dev_w1, acc, 'step2')
+    # test(): inference-mode forward (moving statistics) + loss, no update
+    net._sync_from_trainer()
+    w_now = {k: v.copy() for k, v in net.weights.items()}
+    pred = net.test(xs2 if len(xs2) > 1 else xs2[0], y2)
+    ref = env['orc'].forward(w_now, net.cfg, xs2, np.float32)
+    assert np.abs(pred - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
+    net._sync_from_trainer()
+    assert all(np.array_equal(net.weights[k], w_now[k]) for k in w_now)          # nothing moved
+    yp = net.predict(xs2 if len(xs2) > 1 else xs2[0])
+    assert np.abs(yp - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
+
+
+def test_velocity_head_learns_a_batch(env):
+    """The reference's smallest head (11 conv layers, 36 x 8 input) on a fixed batch of 8 (main.py -batch_size):
+    the first step matches the oracle and thirty steps drive the batch loss down."""
+    p = env['hp'].Hyperparams(N=2048)
+    h = env['heads'].VelocityClassifier(p)
+    rng = np.random.default_rng(4)
+    specs = [(rng.random((36, 8)) ** 2).astype(np.float32) for _ in range(8)]
+    gold = list(rng.uniform(5, 125, 8))
+    x = np.stack(specs)[..., None]
+    w0 = {k: v.copy() for k, v in h.weights.items()}
+    _compare_step(env, h, [x], np.array(gold), w0, None, 'velocity')
+    for _ in range(30):
+        h.classify(specs, gold)
+    losses = [m[0] for m in h.metrics_train]
+    assert len(losses) == 31 and losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    pred = h.classify(specs)
+    assert pred.shape == (8, 1) and np.abs(pred[:, 0] - gold).mean() < np.abs(np.array(gold) - np.mean(gold)).mean()
