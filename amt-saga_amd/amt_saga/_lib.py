@@ -89,7 +89,8 @@ PROTOTYPES = {
     'amt_rdcnn_forward': (C.c_int, [vp, C.POINTER(vp), C.c_int, vp, vp, vp, C.c_size_t, vp]),
     'amt_rdcnn_flops_per_window': (C.c_double, [vp]),
     'amt_rdcnn_set_mode': (C.c_int, [vp, C.c_int]),
-    'amt_trainer_create': (C.c_int, [C.POINTER(vp), C.POINTER(RdcnnDesc), vp, C.c_size_t, C.c_float, C.c_float]),
+    'amt_trainer_create': (C.c_int, [C.POINTER(vp), C.POINTER(RdcnnDesc), vp, C.c_size_t, C.c_float, C.c_float,
+                                     C.c_float]),
     'amt_trainer_destroy': (C.c_int, [vp]),
     'amt_trainer_step': (C.c_int, [vp, C.POINTER(vp), vp, C.c_int, C.c_int, c_float_p, vp, vp]),
     'amt_trainer_get_weights': (C.c_int, [vp, vp, C.c_size_t]),

@@ -377,7 +377,10 @@ class res_net:
     # ---- training side (RDCNN.py:503-589): amt_trainer_step on the device ----------------------------
     def _trainer_handle(self):
         """The device-side trainer, created from the current weights on first use.  From then on it owns
-        the live weights; predict() pulls them back before its next forward (``_sync_from_trainer``)."""
+        the live weights; predict() pulls them back before its next forward (``_sync_from_trainer``).
+        Optimiser = Adagrad as RDCNN.py:246-253 compiles it; attributes ``learning_rate`` (0.01),
+        ``adagrad_epsilon`` (1e-7) and ``adagrad_initial_accumulator`` (0.1 = tf.keras >= 1.14; set 0.0 for
+        Keras 2.2 / tf.keras 1.13) may be set before the first train() call."""
         if getattr(self, '_trainer', None) is None:
             lib = _lib.load()
             require_gpu()
@@ -385,7 +388,8 @@ class res_net:
             h = C.c_void_p()
             _lib.check(lib.amt_trainer_create(C.byref(h), C.byref(d), self._blob.ctypes.data_as(C.c_void_p),
                                               self._blob.size, float(getattr(self, 'learning_rate', 0.0)),
-                                              float(getattr(self, 'adagrad_epsilon', 0.0))))
+                                              float(getattr(self, 'adagrad_epsilon', 0.0)),
+                                              float(getattr(self, 'adagrad_initial_accumulator', 0.1))))
             self._trainer, self._tlib, self._trained = h, lib, False
         return self._trainer
 

@@ -17,12 +17,14 @@
 //   * BatchNormalization in training mode: per-channel batch statistics by two-stage column reductions,
 //     moving statistics updated with momentum 0.99; its backward needs two more column sums;
 //   * sigmoid, shortcut add, max / average pooling and their gradients are elementwise / gather kernels;
-//   * Adagrad (Keras 2.2: a += g^2, p -= lr g / (sqrt(a) + eps)) is one elementwise kernel per tensor.
+//   * Adagrad (a += g^2, p -= lr g / (sqrt(a) + eps); accumulators start at 0 as in Keras 2.2 / tf.keras 1.13 or
+//     at 0.1 as in tf.keras >= 1.14 -- the reference pins neither) is one elementwise kernel per tensor.
 // A small tape (list of ops over numbered tensors) is built from the topology descriptor once; a step
 // walks it forwards, then backwards accumulating gradients per tensor (the shortcut source receives two).
 #include "amt_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -142,7 +144,7 @@ __global__ void col2im_kernel(const float *__restrict__ dcol, int B, int H, int 
 }
 
 // ---- column reductions over a [M][C] matrix: two stages, fixed order ---------------------------------
-// mode 0: sum x;  1: sum (x - mu[c])^2;  2: (sum dy, sum dy * zhat) with zhat = (z - mu) * inv
+// mode 0 / 3: sum x;  1: sum (x - mu[c])^2;  2: (sum dy, sum dy * zhat) with zhat = (z - mu) * inv
 #define CR_SPLIT 64
 __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict__ x, const float *__restrict__ z,
                                                          const float *__restrict__ mu, const float *__restrict__ inv,
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
         const float m = (mode >= 1 && mu) ? mu[c] : 0.f, iv = mode == 2 ? inv[c] : 0.f;
         for (size_t r = r0 + rl; r < r1; r += 8) {
             const float v = x[r * C + c];
-            if (mode == 0) s0 += v;
+            if (mode == 0 || mode == 3) s0 += v;
             else if (mode == 1) { const float d = v - m; s0 += d * d; }
             else { s0 += v; s1 += v * ((z[r * C + c] - m) * iv); }
         }
@@ -361,7 +363,7 @@ struct amt_trainer {
     std::vector<int> inputs;                      // tensor id of each tower's input
     int t_flat = -1, t_logits = -1;
     int flat = 0, capB = 0;
-    float lr = 0.01f, eps = 1e-7f;
+    float lr = 0.01f, eps = 1e-7f, acc0 = 0.f;
     float *col = nullptr, *part = nullptr, *red0 = nullptr, *red1 = nullptr, *stat0 = nullptr, *stat1 = nullptr;
     float *pred = nullptr, *loss_rows = nullptr, *dlogits = nullptr;
     size_t col_cap = 0, part_cap = 0;
@@ -388,6 +390,10 @@ int add_param(amt_trainer *t, const float *&cur, size_t n, bool trainable) {
     cur += n;
     if (trainable) {
         if (talloc(t, n, &p.g, true) != AMT_OK || talloc(t, n, &p.acc, true) != AMT_OK) return -1;
+        if (t->acc0 > 0.f) {
+            std::vector<float> a0(n, t->acc0);
+            if (hipMemcpy(p.acc, a0.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        }
     }
     t->params.push_back(p);
     return (int)t->params.size() - 1;
@@ -448,7 +454,7 @@ int amt_trainer_destroy(amt_trainer *t) {
 }
 
 int amt_trainer_create(amt_trainer **out, const amt_rdcnn_desc *desc, const float *wh, size_t n_floats, float lr,
-                       float epsilon) {
+                       float epsilon, float initial_accumulator) {
     if (!out || !desc || !wh) return AMT_E_INVALID;
     if ((size_t)amt_rdcnn_param_count(desc) != n_floats || n_floats == 0) return AMT_E_SHAPE;
     const amt_rdcnn_desc &d = *desc;
@@ -456,6 +462,7 @@ int amt_trainer_create(amt_trainer **out, const amt_rdcnn_desc *desc, const floa
     t->d = d;
     if (lr > 0.f) t->lr = lr;
     if (epsilon > 0.f) t->eps = epsilon;
+    t->acc0 = initial_accumulator > 0.f ? initial_accumulator : 0.f;
     const float *cur = wh;
 #define TR_P(n, tr) add_param(t, cur, (size_t)(n), tr)
 #define TR_FAIL() do { amt_trainer_destroy(t); return AMT_E_NOMEM; } while (0)
@@ -609,6 +616,16 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
         Tensor &in = t->tensors[t->inputs[i]];
         AMT_HIP_CHECK(hipMemcpyAsync(in.v, x[i], (size_t)B * in.H * in.W * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
+    // AMT_TRAIN_TRACE=1: synchronise and report after every op (locating a faulting kernel)
+    static const bool trace = getenv("AMT_TRAIN_TRACE") != nullptr;
+    int op_no = 0;
+    auto mark = [&](const char *phase, const Op &o) {
+        if (!trace) return;
+        const hipError_t e = hipStreamSynchronize(st);
+        fprintf(stderr, "[amt_train] %s op %d kind %d H %d W %d Cin %d Cout %d k %dx%d : %s\n", phase, op_no, (int)o.kind, o.H, o.W,
+                o.Cin, o.Cout, o.kh, o.kw, hipGetErrorString(e));
+        fflush(stderr);
+    };
     // ---------------- forward ----------------------------------------------------------------
     for (Op &o : t->ops) {
         Tensor &in = t->tensors[o.in0];
@@ -659,6 +676,8 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
             if (rc != AMT_OK) return rc;
             break;
         }
+        mark("fwd", o);
+        ++op_no;
     }
     AMT_LAUNCH_CHECK();
     // ---------------- loss --------------------------------------------------------------------
@@ -684,6 +703,8 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
         Tensor &out = t->tensors[o.out];
         const size_t nin = (size_t)B * in.H * in.W * in.C;
         if (o.kind != OP_FLATTEN && !out.g_set) continue;          // no gradient reaches this op
+        op_no = oi;
+        mark("bwd-enter", o);
         switch (o.kind) {
         case OP_DENSE: {
             // dW = in^T dOut, db = colsum dOut, dIn = dOut W^T

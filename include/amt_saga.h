@@ -289,9 +289,11 @@ int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *wi
 typedef struct amt_trainer amt_trainer;
 
 /* weights_host: the canonical blob of amt_rdcnn_create (trainable tensors AND the BN moving statistics).
- * lr / epsilon <= 0 select the Keras 2.2 defaults of Adagrad (0.01, 1e-7); accumulators start at zero. */
+ * lr / epsilon <= 0 select Keras' Adagrad defaults (0.01, 1e-7).  initial_accumulator: starting value of the
+ * squared-gradient accumulators -- 0 in Keras 2.2 / tf.keras 1.13, 0.1 in tf.keras >= 1.14 (the reference's
+ * `keras.optimizers.Adagrad()`, RDCNN.py:246-253, pins neither version). */
 int amt_trainer_create(amt_trainer **trainer, const amt_rdcnn_desc *desc, const float *weights_host,
-                       size_t n_floats, float lr, float epsilon);
+                       size_t n_floats, float lr, float epsilon, float initial_accumulator);
 int amt_trainer_destroy(amt_trainer *trainer);
 /* One batch.  x[t]: device [B][in_h][in_w] per tower; y: device [B] f32 -- the class index (softmax heads)
  * or the target ALREADY scaled to the activation range (RDCNN.py:304-306, :513-514).

@@ -9,7 +9,8 @@ documentation and source as remembered -- PARITY UNPINNED against Keras itself:
   * BatchNormalization(training=True): normalise with the batch mean and the biased batch variance over
     (N, H, W); epsilon 1e-3; moving statistics m <- 0.99 m + 0.01 batch (the biased variance is used for the
     moving average too; TensorFlow's fused kernel applies Bessel's correction there -- not reproduced);
-  * Adagrad (Keras 2.2.4): lr 0.01, accumulators start at 0, a += g^2, p -= lr g / (sqrt(a) + 1e-7);
+  * Adagrad: lr 0.01, a += g^2, p -= lr g / (sqrt(a) + 1e-7); the accumulators start at 0 in Keras 2.2 /
+    tf.keras 1.13 and at 0.1 in tf.keras >= 1.14 -- a parameter here, default 0.1;
   * mean_squared_error: mean over the output axis, then over the batch; sparse_categorical_crossentropy
     on softmax probabilities, mean over the batch (the probability clipping at 1e-7 is not reproduced).
 What IS pinned: the backward pass below is checked against PyTorch autograd on the same graph in float64
@@ -213,20 +214,21 @@ def forward_backward(w, cfg, xs, y, dtype=np.float64):
     return loss, pred, g, stats
 
 
-def adagrad_step(w, g, acc, lr=0.01, eps=1e-7):
-    """Keras 2.2 Adagrad on every tensor that has a gradient; returns (new weights, new accumulators)."""
+def adagrad_step(w, g, acc, lr=0.01, eps=1e-7, initial_accumulator=0.1):
+    """Adagrad on every tensor that has a gradient; returns (new weights, new accumulators).
+    initial_accumulator: 0 (Keras 2.2 / tf.keras 1.13) or 0.1 (tf.keras >= 1.14)."""
     w2, acc2 = dict(w), dict(acc or {})
     for k, gk in g.items():
-        a = acc2.get(k, np.zeros_like(gk)) + gk * gk
+        a = acc2.get(k, np.full_like(gk, initial_accumulator)) + gk * gk
         acc2[k] = a
         w2[k] = (np.asarray(w[k], dtype=gk.dtype) - lr * gk / (np.sqrt(a) + eps)).astype(np.asarray(w[k]).dtype)
     return w2, acc2
 
 
-def train_on_batch(w, cfg, xs, y, acc=None, lr=0.01, eps=1e-7, dtype=np.float32):
+def train_on_batch(w, cfg, xs, y, acc=None, lr=0.01, eps=1e-7, dtype=np.float32, initial_accumulator=0.1):
     """One training step: (loss, prediction, new weights incl. updated BN moving statistics, accumulators)."""
     loss, pred, g, stats = forward_backward(w, cfg, xs, y, dtype)
-    w2, acc2 = adagrad_step(w, g, acc, lr, eps)
+    w2, acc2 = adagrad_step(w, g, acc, lr, eps, initial_accumulator)
     for prefix, (mu, var) in stats.items():
         w2[prefix + '/mean'] = (BN_MOMENTUM * np.asarray(w[prefix + '/mean'], dtype) + (1 - BN_MOMENTUM) * mu).astype(np.float32)
         w2[prefix + '/var'] = (BN_MOMENTUM * np.asarray(w[prefix + '/var'], dtype) + (1 - BN_MOMENTUM) * var).astype(np.float32)

@@ -281,7 +281,8 @@ def test_classify_contract(env):
     # with gold: one training step on the batch (velocity_classifier.py:48-55); with test_phase: no update
     w0 = {k: v.copy() for k, v in h.weights.items()}
     yt = h.classify(spec, [40, 50, 60, 70], test_phase=True)
-    assert yt.shape == (4, 1) and np.array_equal(yt, y) and len(h.metrics_test) == 1
+    # (test() runs the trainer's inference-mode forward -- im2col + f32 GEMM -- not the fused conv kernels)
+    assert yt.shape == (4, 1) and np.abs(yt - y).max() < 1e-4 * np.abs(y).max() and len(h.metrics_test) == 1
     ytr = h.classify(spec, [40, 50, 60, 70])
     assert ytr.shape == (4, 1) and len(h.metrics_train) == 1 and h.current_batch == 2
     y2 = h.classify(spec)                                   # predict pulls the trained weights back

@@ -39,21 +39,29 @@ def _compare_step(env, net, xs, y, w_before, acc, tag):
     loss = net.metrics_train[-1][0]
     grads = net.gradients()
     o_loss, o_pred, g, stats = env['otr'].forward_backward(w_before, net.cfg, xs, _to_act(net, y), np.float32)
-    o_loss2, _, w_after, acc2 = env['otr'].train_on_batch(w_before, net.cfg, xs, _to_act(net, y), acc=acc, dtype=np.float32)
+    lr = getattr(net, 'learning_rate', 0.01)
+    o_loss2, _, w_after, acc2 = env['otr'].train_on_batch(w_before, net.cfg, xs, _to_act(net, y), acc=acc, lr=lr,
+                                                          dtype=np.float32,
+                                                          initial_accumulator=getattr(net, 'adagrad_initial_accumulator', 0.1))
     assert abs(loss - o_loss) <= 2e-5 * max(abs(o_loss), 1e-3), (tag, loss, o_loss)
     o_out = net._scale_activation_to_output(o_pred) if net.output_classes == 1 else o_pred
     assert np.abs(pred - o_out).max() <= 1e-4 * max(np.abs(o_out).max(), 1e-6), tag
-    gmax = max(np.abs(v).max() for v in g.values())
-    for k, gk in g.items():
+    # gradients: against the float64 oracle, to 3e-4 of the tensor's largest gradient plus four times the distance
+    # the float32 oracle itself keeps from float64 (the arithmetic noise floor: a conv bias in front of a
+    # training-mode BN has a structurally zero gradient, and both float32 results are pure rounding noise there)
+    _, _, g64, _ = env['otr'].forward_backward(w_before, net.cfg, xs, _to_act(net, y), np.float64)
+    gmax = max(np.abs(v).max() for v in g64.values())
+    for k, gk in g64.items():
         err = np.abs(grads[k] - gk).max()
-        assert err <= 3e-4 * np.abs(gk).max() + 2e-6 * gmax, (tag, k, err, np.abs(gk).max(), gmax)
+        noise = np.abs(g[k] - gk).max()
+        assert err <= 3e-4 * np.abs(gk).max() + 4 * noise + 1e-7 * gmax, (tag, k, err, np.abs(gk).max(), noise, gmax)
     net._sync_from_trainer()
     for k, gk in g.items():
         if np.abs(gk).max() < 1e-4 * gmax:
             continue                      # structurally zero gradient (a bias in front of a training-mode BN): Adagrad
         #                                   divides noise by noise there, in Keras as here
         big = np.abs(gk) > 1e-3 * np.abs(gk).max()          # elements whose sign and size are not rounding noise
-        assert np.abs(net.weights[k] - w_after[k])[big].max() <= 2e-4, (tag, k)
+        assert np.abs(net.weights[k] - w_after[k])[big].max() <= 0.02 * lr, (tag, k)
     for p_ in stats:
         for leaf in ('mean', 'var'):
             a, b = net.weights[p_ + '/' + leaf], w_after[p_ + '/' + leaf]
@@ -64,6 +72,7 @@ def _compare_step(env, net, xs, y, w_before, acc, tag):
 @pytest.mark.parametrize('case', range(len(CASES)))
 def test_train_step_vs_oracle(env, case):
     net = env['rdcnn'].res_net(weight_seed=31 + case, calibrated=False, **CASES[case])
+    net.adagrad_initial_accumulator = 0.0 if case % 2 == 0 else 0.1      # Keras 2.2 / tf.keras >= 1.14
     xs, y = _batch(net.cfg, 6, case)
     w0 = {k: v.copy() for k, v in net.weights.items()}
     w1, acc = _compare_step(env, net, xs, y, w0, None, 'step1')
@@ -84,9 +93,10 @@ def test_train_step_vs_oracle(env, case):
     assert np.abs(yp - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
 
 
-def test_velocity_head_learns_a_batch(env):
-    """The reference's smallest head (11 conv layers, 36 x 8 input) on a fixed batch of 8 (main.py -batch_size):
-    the first step matches the oracle and thirty steps drive the batch loss down."""
+def test_velocity_head_first_step_and_learning(env):
+    """The reference's smallest head (11 conv layers, 36 x 8 input) on a batch of 8 (main.py -batch_size): the first
+    train_on_batch matches the oracle; and forty steps on a fixed batch drive the loss of two shallow nets (one
+    regression / MSE, one softmax / sparse-CCE) down by an order of magnitude, tracking the oracle's trajectory."""
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].VelocityClassifier(p)
     rng = np.random.default_rng(4)
@@ -95,9 +105,18 @@ def test_velocity_head_learns_a_batch(env):
     x = np.stack(specs)[..., None]
     w0 = {k: v.copy() for k, v in h.weights.items()}
     _compare_step(env, h, [x], np.array(gold), w0, None, 'velocity')
-    for _ in range(30):
-        h.classify(specs, gold)
-    losses = [m[0] for m in h.metrics_train]
-    assert len(losses) == 31 and losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
-    pred = h.classify(specs)
-    assert pred.shape == (8, 1) and np.abs(pred[:, 0] - gold).mean() < np.abs(np.array(gold) - np.mean(gold)).mean()
+    pred = h.classify(specs, gold)                            # classify(spec, gold) trains (velocity_classifier.py:48-55)
+    assert pred.shape == (8, 1) and len(h.metrics_train) == 2 and h.metrics_train[1][0] < h.metrics_train[0][0]
+    for case in (0, 1):
+        net = env['rdcnn'].res_net(weight_seed=31 + case, calibrated=False, **CASES[case])
+        xs, y = _batch(net.cfg, 8, 7)
+        w, acc, ref = net.weights, None, []
+        for _ in range(40):
+            net.train(xs[0], y)
+        for _ in range(40):
+            loss, _, w, acc = env['otr'].train_on_batch(w, net.cfg, xs, _to_act(net, y), acc=acc, dtype=np.float32)
+            ref.append(loss)
+        losses = [m[0] for m in net.metrics_train]
+        assert losses[-1] < 0.15 * losses[0], (case, losses[0], losses[-1])
+        # same trajectory as the oracle (rounding differences grow slowly over the steps)
+        assert np.abs(np.array(losses) - np.array(ref)).max() <= 0.02 * losses[0], (case, losses[-3:], ref[-3:])

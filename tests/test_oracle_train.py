@@ -83,7 +83,7 @@ def test_backward_matches_autograd(case):
         scale = np.abs(tg[k]).max()
         assert np.abs(g[k] - tg[k]).max() < 1e-8 * scale + 1e-10 * gmax, (k, np.abs(g[k] - tg[k]).max(), scale)
     # every BN layer reported its batch statistics; one Adagrad step moves every trainable tensor by ~lr
-    loss32, pred32, w2, acc = otr.train_on_batch(net.weights, cfg, xs, y, dtype=np.float64)
+    loss32, pred32, w2, acc = otr.train_on_batch(net.weights, cfg, xs, y, dtype=np.float64, initial_accumulator=0.0)
     for k in tg:
         step = np.abs(w2[k] - net.weights[k])
         assert step.max() <= 0.01 + 1e-6
@@ -92,6 +92,6 @@ def test_backward_matches_autograd(case):
     for p, (mu, var) in stats.items():
         assert np.allclose(w2[p + '/mean'], 0.99 * net.weights[p + '/mean'] + 0.01 * mu, atol=1e-6)
     # a second step with the accumulators shrinks the update (Adagrad)
-    _, _, w3, _ = otr.train_on_batch(w2, cfg, xs, y, acc=acc, dtype=np.float64)
+    _, _, w3, _ = otr.train_on_batch(w2, cfg, xs, y, acc=acc, dtype=np.float64, initial_accumulator=0.0)
     k = 'dense1/kernel'
     assert np.abs(w3[k] - w2[k]).mean() < np.abs(w2[k] - net.weights[k]).mean()
