@@ -1498,7 +1498,7 @@ int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *wi
     return AMT_OK;
 }
 
-#define RD_CHUNK 512
+#define RD_CHUNK 1024
 static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     size_t ma = 0;
     for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);

@@ -299,7 +299,7 @@ def main():
             pmc = json.load(open(tf))
             t = pmc.get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
             if t:
-                traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 512))
+                traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 1024))     # windows per launch (RD_CHUNK)
         except Exception:
             traffic = None
     roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=peak_tf, unit='TFLOP/s',

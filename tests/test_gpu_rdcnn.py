@@ -212,26 +212,26 @@ def test_split_fp16_operand_range(env):
     assert float((l2 - l0).abs().max()) / max(float(l0.abs().max()), 1.0) < 2e-5
 
 
-def test_chunk_boundary_520_windows(env):
-    """A 520-window batch crosses the 512-window chunk of amt_rdcnn_forward (second chunk: 8 windows, the
+def test_chunk_boundary_1030_windows(env):
+    """A 1030-window batch crosses the 1024-window chunk of amt_rdcnn_forward (second chunk: 6 windows, the
     workspace is reused): every window's logits are bit-identical to a small batch of the same windows, in
     all three arithmetics, and an oracle subset straddling the boundary agrees."""
     torch = env['torch']
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].pitch_classifier(p)
     cfg = env['orc'].head_config(p, 'pitch')
-    x = _inputs((174, 8), 520, 23)
+    x = _inputs((174, 8), 1030, 23)
     xd = torch.from_numpy(x).cuda()
-    pick = [0, 255, 509, 510, 511, 512, 513, 519]
+    pick = [0, 511, 512, 1021, 1022, 1023, 1024, 1025, 1029]
     xs = torch.from_numpy(x[pick]).cuda()
     for mode in (0, 1, 2):
         h.set_mode(mode)
         y, lg = h.predict_device([xd], return_logits=True)
         ys, lgs = h.predict_device([xs], return_logits=True)
         assert torch.equal(lg[pick], lgs) and torch.equal(y[pick], ys), mode
-        tail, lgt = h.predict_device([xd[508:].contiguous()], return_logits=True)
-        assert torch.equal(lg[508:], lgt), mode
-    sub = [509, 511, 512, 519]
+        tail, lgt = h.predict_device([xd[1020:].contiguous()], return_logits=True)
+        assert torch.equal(lg[1020:], lgt), mode
+    sub = [1021, 1023, 1024, 1029]
     ref = env['orc'].forward(h.weights, cfg, [x[sub][..., None]], np.float32, return_logits=True)
     assert np.abs(lg[sub].cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1.0) < REL
     # the outputs move with the input (calibrated synthetic weights): not a constant function
