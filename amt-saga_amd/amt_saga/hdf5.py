@@ -329,3 +329,148 @@ class File:
             else:
                 out.append(q)
         return out
+
+
+# =====================================================================================================
+# Writer: the subset above, enough for Keras ``load_weights`` / h5py / libhdf5 to open the result
+# =====================================================================================================
+UNDEF = 0xFFFFFFFFFFFFFFFF
+_LEAF_K, _INTERNAL_K = 64, 16            # symbol-table node holds 2 * 64 names, one B-tree node 2 * 16 of those
+
+
+def _pad8(b):
+    return b + bytes((-len(b)) % 8)
+
+
+def _dt_float(size):
+    if size == 4:
+        props = struct.pack('<HHBBBBI', 0, 32, 23, 8, 0, 23, 127)
+        return struct.pack('<BBBBI', 0x11, 0x20, 31, 0, 4) + props
+    props = struct.pack('<HHBBBBI', 0, 64, 52, 11, 0, 52, 1023)
+    return struct.pack('<BBBBI', 0x11, 0x20, 63, 0, 8) + props
+
+
+def _dt_string(n):
+    return struct.pack('<BBBBI', 0x13, 0x01, 0, 0, n)        # fixed length, null padded, ASCII
+
+
+def _w_dataspace(shape):
+    if shape is None:                                         # scalar
+        return struct.pack('<BBB5x', 1, 0, 0)
+    return struct.pack('<BBB5x', 1, len(shape), 0) + b''.join(struct.pack('<Q', int(d)) for d in shape)
+
+
+def _message(mtype, body, flags=0):
+    body = _pad8(body)
+    return struct.pack('<HHB3x', mtype, len(body), flags) + body
+
+
+def _attribute(name, value):
+    """Attribute message (version 1) for bytes (scalar fixed string), a list of bytes (1-D fixed strings)
+    or an empty list (Keras writes np.asarray([]) -> float64, shape (0,))."""
+    nm = name.encode('utf8') + b'\x00'
+    if isinstance(value, bytes):
+        dt, sp, data = _dt_string(max(len(value), 1)), _w_dataspace(None), value or b'\x00'
+    elif len(value) == 0:
+        dt, sp, data = _dt_float(8), _w_dataspace((0,)), b''
+    else:
+        w = max(len(v) for v in value)
+        dt, sp = _dt_string(w), _w_dataspace((len(value),))
+        data = b''.join(v.ljust(w, b'\x00') for v in value)
+    body = struct.pack('<BBHHH', 1, 0, len(nm), len(dt), len(sp)) + _pad8(nm) + _pad8(dt) + _pad8(sp) + data
+    if len(body) > 64000:
+        raise ValueError('HDF5: attribute %s exceeds the object-header message limit' % name)
+    return _message(0x000C, body)
+
+
+def _object_header(messages):
+    body = b''.join(messages)
+    return struct.pack('<BBHII4x', 1, 0, len(messages), 1, len(body)) + body
+
+
+class Writer:
+    """Builds an HDF5 file in memory: ``w = Writer(); w.group('/a', attrs={...}); w.dataset('/a/a/k:0', array);
+    w.save(path)``.  Parent groups are created on demand.  float32 / float64 datasets, contiguous layout."""
+
+    def __init__(self):
+        self.groups = {'/': {}}                    # path -> attrs (insertion order irrelevant: names are sorted on disk)
+        self.datasets = {}                         # path -> ndarray
+
+    def group(self, path, attrs=None):
+        path = '/' + path.strip('/')
+        parts = [p for p in path.split('/') if p]
+        for i in range(len(parts)):
+            self.groups.setdefault('/' + '/'.join(parts[:i + 1]), {})
+        self.groups[path if parts else '/'].update(attrs or {})
+
+    def attrs(self, path, attrs):
+        self.group(path, attrs)
+
+    def dataset(self, path, array):
+        path = '/' + path.strip('/')
+        parent = path.rsplit('/', 1)[0] or '/'
+        self.group(parent)
+        a = np.ascontiguousarray(array)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float32)
+        self.datasets[path] = a
+
+    def save(self, path):
+        out = bytearray(96)                        # superblock, patched at the end
+        addr = {}
+
+        def alloc(b):
+            a = len(out)
+            out.extend(_pad8(b))
+            return a
+
+        # datasets first (raw data, then headers)
+        for p, a in self.datasets.items():
+            raw = alloc(a.astype('<f%d' % a.dtype.itemsize).tobytes()) if a.size else UNDEF
+            msgs = [_message(0x0001, _w_dataspace(a.shape)), _message(0x0003, _dt_float(a.dtype.itemsize), 1),
+                    _message(0x0005, bytes([2, 2, 2, 1, 0, 0, 0, 0])),
+                    _message(0x0008, struct.pack('<BBQQ', 3, 1, raw, a.size * a.dtype.itemsize))]
+            addr[p] = alloc(_object_header(msgs))
+        # groups bottom-up (children's addresses are needed by the parent's symbol table)
+        for g in sorted(self.groups, key=lambda s: -s.count('/') if s != '/' else 1):
+            prefix = '' if g == '/' else g
+            kids = sorted({p[len(prefix) + 1:] for p in list(self.groups) + list(self.datasets)
+                           if p != g and p.startswith(prefix + '/') and '/' not in p[len(prefix) + 1:]},
+                          key=lambda s: s.encode('utf8'))
+            if len(kids) > 2 * _LEAF_K * 2 * _INTERNAL_K:
+                raise ValueError('HDF5: too many links in one group')
+            heap = bytearray(8)                    # offset 0: the empty name
+            offs = {}
+            for k in kids:
+                offs[k] = len(heap)
+                heap += _pad8(k.encode('utf8') + b'\x00')
+            free_off = len(heap)
+            heap += struct.pack('<QQ', 1, 32) + bytes(16)          # one free block closes the heap
+            heap_data = alloc(bytes(heap))
+            heap_addr = alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_off, heap_data))
+            snods, keys = [], [0]
+            for i in range(0, len(kids), 2 * _LEAF_K):
+                chunk = kids[i:i + 2 * _LEAF_K]
+                body = b'SNOD' + struct.pack('<BBH', 1, 0, len(chunk))
+                for k in chunk:
+                    body += struct.pack('<QQII16x', offs[k], addr[(prefix + '/' + k)], 0, 0)
+                body += bytes(40 * (2 * _LEAF_K - len(chunk)))
+                snods.append(alloc(body))
+                keys.append(offs[chunk[-1]])
+            node = b'TREE' + struct.pack('<BBHQQ', 0, 0, len(snods), UNDEF, UNDEF)
+            for i in range(2 * _INTERNAL_K):
+                node += struct.pack('<Q', keys[i] if i < len(keys) else 0)
+                node += struct.pack('<Q', snods[i] if i < len(snods) else 0)
+            node += struct.pack('<Q', keys[len(snods)] if len(snods) < len(keys) and len(snods) == 2 * _INTERNAL_K else 0)
+            btree = alloc(node)
+            msgs = [_message(0x0011, struct.pack('<QQ', btree, heap_addr))]
+            msgs += [_attribute(k, v) for k, v in self.groups[g].items()]
+            addr[g] = alloc(_object_header(msgs))
+            if g == '/':
+                root = (addr[g], btree, heap_addr)
+        sb = SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack('<HHI', _LEAF_K, _INTERNAL_K, 0)
+        sb += struct.pack('<QQQQ', 0, UNDEF, len(out), UNDEF)
+        sb += struct.pack('<QQII', 0, root[0], 1, 0) + struct.pack('<QQ', root[1], root[2])
+        out[:96] = sb
+        with open(path, 'wb') as fh:
+            fh.write(bytes(out))

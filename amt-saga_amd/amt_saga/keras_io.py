@@ -114,3 +114,81 @@ def load_keras_weights(path, layout):
         raise ValueError('Invalid Input shape. Expected: {} weighted layers . Got: {} more ({})'.format(
             len(creation_plan(layout)), len(left), ', '.join(left[:4])))
     return w
+
+
+# ---- export: the same file Keras' save_weights would write for this graph -------------------------------
+def keras_layers(cfg):
+    """[(layer name, canonical prefix or None)] in ``model.layers`` order for the graph RDCNN.py:176-233 builds:
+    names ``<class>_<n>`` from per-class creation counters (Keras' automatic naming), order by graph depth
+    (longest path to the output, as keras.engine.network sorts its layers), ties by creation."""
+    counters, nodes = {}, []
+
+    def new(cls, prefix, inputs):
+        counters[cls] = counters.get(cls, 0) + 1
+        nodes.append(('%s_%d' % (cls, counters[cls]), prefix, list(inputs)))
+        return len(nodes) - 1
+
+    rf = cfg['residual_layer_frequencies']
+    r = rf[0] if rf else 0
+    tails = []
+    for t, (H, W, _) in enumerate(cfg['input_shapes']):
+        cur = new('input', None, [])
+        ph, pw = cfg['pool_sizes'][t]
+        C, fo = 1, 32
+        p0, p0_shape = cur, (H, W, 1)
+        for i in range(1, cfg['convolutional_layer_count'] + 1):
+            cur = new('conv2d', 't%d/conv%d' % (t, i), [cur])
+            cur = new('batch_normalization', 't%d/bn%d' % (t, i), [cur])
+            cur = new('activation', None, [cur])
+            C = fo
+            if r and i % r == 0:
+                a = p0
+                if p0_shape != (H, W, C):
+                    if p0_shape[2] != C:
+                        a = new('conv2d', 't%d/sc%d' % (t, i), [a])
+                    if p0_shape[:2] != (H, W):
+                        a = new('average_pooling2d', None, [a])
+                    a = new('batch_normalization', 't%d/scbn%d' % (t, i), [a])
+                cur = new('add', None, [a, cur])
+                cur = new('batch_normalization', 't%d/resbn%d' % (t, i), [cur])
+                p0, p0_shape = cur, (H, W, C)
+            if cfg['pool_layer_frequency'] and i % cfg['pool_layer_frequency'] == 0:
+                cur = new('max_pooling2d', None, [cur])
+                H, W = H // ph, W // pw
+            if cfg['feature_expand_frequency'] and i % cfg['feature_expand_frequency'] == 0:
+                fo *= 2
+        tails.append(new('flatten', None, [cur]))
+    m = tails[0] if len(tails) == 1 else new('concatenate', None, tails)
+    m = new('dense', 'dense1', [m])
+    m = new('activation', None, [m])
+    m = new('dense', 'dense2', [m])
+    new('activation', None, [m])
+    depth = [0] * len(nodes)
+    for idx in range(len(nodes) - 1, -1, -1):
+        for j in nodes[idx][2]:
+            depth[j] = max(depth[j], depth[idx] + 1)
+    order = sorted(range(len(nodes)), key=lambda k: (-depth[k], k))
+    return [(nodes[k][0], nodes[k][1]) for k in order]
+
+
+def save_keras_weights(path, weights, cfg, keras_version=b'2.2.4-tf', backend=b'tensorflow'):
+    """Write `weights` (canonical dict) as the HDF5 file ``model.save_weights(path)`` produces for the reference's
+    graph (RDCNN.py:490-494): root attributes layer_names / backend / keras_version, one group per layer with its
+    weight_names, datasets <layer>/<layer>/<weight>:0 -- so that Keras' ``load_weights`` (RDCNN.py:778-782) and
+    this build's importer both take it."""
+    w = hdf5.Writer()
+    layers = keras_layers(cfg)
+    w.group('/', {'layer_names': [n.encode('utf8') for n, _ in layers], 'backend': backend, 'keras_version': keras_version})
+    for name, prefix in layers:
+        if prefix is None:
+            w.group('/' + name, {'weight_names': []})
+            continue
+        if name.startswith('batch_normalization'):
+            keys = (('gamma', 'gamma'), ('beta', 'beta'), ('moving_mean', 'mean'), ('moving_variance', 'var'))
+        else:
+            keys = (('kernel', 'kernel'), ('bias', 'bias'))
+        w.group('/' + name, {'weight_names': [('%s/%s:0' % (name, k)).encode('utf8') for k, _ in keys]})
+        for k, ours in keys:
+            w.dataset('/%s/%s/%s:0' % (name, name, k), np.asarray(weights[prefix + '/' + ours], dtype=np.float32))
+    w.save(path)
+

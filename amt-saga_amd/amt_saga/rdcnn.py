@@ -300,7 +300,14 @@ class res_net:
             self.set_weights({k: z[k] for k in z.files})
 
     def save_weights(self, filename):
-        np.savez(filename, **self.weights)
+        """'.h5' / '.hdf5': the Keras ``save_weights`` file of this graph (RDCNN.py:490-494; loadable by the
+        reference's ``load_weights``); otherwise this build's '.npz'."""
+        self._sync_from_trainer()
+        if str(filename).endswith(('.h5', '.hdf5')):
+            from .keras_io import save_keras_weights
+            save_keras_weights(filename, self.weights, self.cfg)
+        else:
+            np.savez(filename, **self.weights)
 
     @property
     def flops_per_window(self):
@@ -471,11 +478,10 @@ class res_net:
                     break
 
     def save_checkpoint(self):                              # RDCNN.py:467-501
-        """Weights of the current batch index as '<dir>/<prefix>_<batch>.npz' (the reference writes a Keras
-        .h5; this build reads those -- load_weights -- and writes its own .npz)."""
+        """Weights of the current batch index as '<dir>/<prefix>_<batch>.h5', the file name and format the
+        reference writes (RDCNN.py:490-494; its metrics bookkeeping is out of scope)."""
         import os as _os
-        self._sync_from_trainer()
         _os.makedirs(self.checkpoint_dir, exist_ok=True)
-        path = _os.path.join(self.checkpoint_dir, '%s_%d.npz' % (self.checkpoint_prefix, self.current_batch))
+        path = _os.path.join(self.checkpoint_dir, '%s_%d.h5' % (self.checkpoint_prefix, self.current_batch))
         self.save_weights(path)
         return path

@@ -84,3 +84,43 @@ def test_npz_round_trip(tmp_path):
     other = res_net(calibrated=False, **kw)
     other.load_weights(path)
     assert all(np.array_equal(other.weights[k], net.weights[k]) for k in net.weights)
+
+
+@pytest.mark.parametrize('tag', sorted(gen.CASES))
+def test_save_weights_writes_the_keras_file(tmp_path, golden_dir, tag):
+    """res_net.save_weights('x.h5') (the reference's checkpoint format, RDCNN.py:490-494) through the build's own
+    HDF5 writer: same layers, attributes and datasets as the fixture the real HDF5 library wrote from an
+    independent restatement of Keras' layout; readable back bit-exactly; and, where the HDF5 tools exist
+    (/opt/conda/bin/h5ls in this image), accepted by libhdf5 itself."""
+    import shutil, subprocess
+    kw = dict(gen.CASES[tag])
+    net = res_net(calibrated=False, **kw)
+    path = str(tmp_path / ('checkpoint_%s_7.h5' % tag))
+    net.save_weights(path)
+    ours, ours_order = keras_io.read_layers(path)
+    ref, ref_order = keras_io.read_layers(os.path.join(golden_dir, 'keras_weights_%s.h5' % tag))
+    assert ours_order == ref_order                          # model.layers order, automatic names
+    assert {k: sorted(v) for k, v in ours.items()} == {k: sorted(v) for k, v in ref.items()}
+    for ln in ref:
+        for k in ref[ln]:
+            assert np.array_equal(ours[ln][k], ref[ln][k]), (ln, k)
+    fo, fr = hdf5.File(path), hdf5.File(os.path.join(golden_dir, 'keras_weights_%s.h5' % tag))
+    assert fo.attrs('/')['backend'] == fr.attrs('/')['backend'] and sorted(fo.visit()) == sorted(fr.visit())
+    kw['weight_seed'] = 4321
+    other = res_net(calibrated=False, **kw)
+    other.load_weights(path)
+    assert all(np.array_equal(other.weights[k], net.weights[k]) for k in net.weights)
+    h5ls = shutil.which('h5ls') or '/opt/conda/bin/h5ls'
+    if os.path.exists(h5ls):
+        r = subprocess.run([h5ls, '-r', path], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stderr.strip() == ''
+        listed = {l.split()[0] for l in r.stdout.splitlines() if ' Dataset ' in l}
+        assert listed == set(fo.visit())
+
+
+def test_save_checkpoint_name(tmp_path):
+    net = res_net(calibrated=False, checkpoint_dir=str(tmp_path), checkpoint_prefix='checkpoint_pitch',
+                  starting_checkpoint_index=500, **gen.CASES['shallow'])
+    p = net.save_checkpoint()
+    assert os.path.basename(p) == 'checkpoint_pitch_500.h5' and hdf5.File(p).attrs('/')['keras_version'] == b'2.2.4-tf'
+
