@@ -276,6 +276,20 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     return out
 
 
+def cqt_window_max(wave, table, hop):
+    """max over every bin of `table` and every STFT-grid frame 0 .. L // hop of the windows' CQT: the song-level
+    normalisers np.max(slice_C(0, duration, n_frames, ...)) of training.py:271-282.  wave [B, L] f32 device;
+    table from cqt_table(..., device).  Returns [B]."""
+    lib = _lib.load()
+    B, L = wave.shape
+    out = empty((B,))
+    n_bins = int(table[0].shape[0])
+    coef = empty((n_bins, 192))
+    _lib.check(lib.amt_cqt_window_max(ptr(wave), B, L, _stride0(wave), int(hop), ptr(table[0]), ptr(table[1]),
+                                      n_bins, ptr(coef), ptr(out), stream_ptr()))
+    return out
+
+
 FILTER_SCALE = 2.0     # slice_C hard-codes filter_scale=2 (util_audio.py:426)
 
 

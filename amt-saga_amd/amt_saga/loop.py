@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import _lib, synth
-from .audio import AudioBatch, cqt_slices, cqt_table, midi_to_hz
+from .audio import AudioBatch, cqt_slices, cqt_table, cqt_window_max, midi_to_hz
 from .device import empty, ptr, require_gpu, stream_ptr, to_dev, zeros
 from .heads import (InstrumentClassifier, VelocityClassifier, pitch_classifier,
                     timming_classifier)
@@ -42,13 +42,12 @@ EVENT_FIELDS = ('window', 'iter', 'pitch', 'program', 'velocity', 'onset_frame',
 
 class TranscriptionLoop:
     def __init__(self, params, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True,
-                 groups=(0,), ref_frames=8, seeds=None, guess='bank'):
+                 groups=(0,), seeds=None, guess='bank'):
         self.p = params
         self.heads = tuple(heads)
         self.iters = int(iters)
         self.do_subtract = bool(subtract)
         self.groups = tuple(groups)
-        self.ref_frames = int(ref_frames)
         if guess not in ('bank', 'render'):
             raise ValueError('Requested attribute does not exist')
         self.guess = guess
@@ -124,27 +123,11 @@ class TranscriptionLoop:
                                              stream_ptr()))
         return out
 
-    def _cqt_max(self, wave, table, n_bins, T):
-        """max over a frame subset of the window's CQT (song-level ref_C_*)."""
-        B = wave.shape[0]
-        nf = min(self.ref_frames, T)
-        frames = np.unique(np.linspace(0, T - 1, nf).round().astype(np.int32))
-        best = None
-        for c0 in range(0, len(frames), 8):
-            cols = frames[c0:c0 + 8]
-            if len(cols) < 8:
-                cols = np.concatenate([cols, np.full(8 - len(cols), -1, np.int32)])
-            src = to_dev(np.tile(cols[None], (B, 1)), torch.int32)
-            o = cqt_slices(wave, src, table, n_bins, self.p.H)
-            m = empty((B,))
-            _lib.check(self.lib.amt_window_max(ptr(o), B, n_bins, 8, n_bins * 8, ptr(m), stream_ptr()))
-            best = m if best is None else torch.maximum(best, m)
-        return best
-
     # ---- per batch ------------------------------------------------------------------------
     def prepare(self, wave, refs=None):
-        """STFT of the windows + the song-level constants.  `refs` may supply
-        dict(ref_mag, ref_C_1, ref_C_inst, ref_C_foc) tensors [B]."""
+        """STFT of the windows + the song-level constants (training.py:269-282; each window stands for its
+        song): ref_mag = max |STFT|, ref_C_* = max over every bin and every frame of the normaliser's CQT
+        grid.  `refs` may supply dict(ref_mag, ref_C_1, ref_C_inst, ref_C_foc) tensors [B]."""
         if not self._dev_ready:
             self.setup_device()
         p = self.p
@@ -159,11 +142,11 @@ class TranscriptionLoop:
         need_cqt = any(h in self.heads for h in ('pitch', 'instrument', 'velocity'))
         if need_cqt:
             if 'pitch' in self.heads and 'ref_C_1' not in refs:
-                refs['ref_C_1'] = self._cqt_max(b.wave, self.tab_ref1, self.tab_ref1[0].shape[0], b.T)
+                refs['ref_C_1'] = cqt_window_max(b.wave, self.tab_ref1, p.H)
             if 'instrument' in self.heads and 'ref_C_inst' not in refs:
-                refs['ref_C_inst'] = self._cqt_max(b.wave, self.tab_refi, self.tab_refi[0].shape[0], b.T)
+                refs['ref_C_inst'] = cqt_window_max(b.wave, self.tab_refi, p.H)
             if 'velocity' in self.heads and 'ref_C_foc' not in refs:
-                refs['ref_C_foc'] = self._cqt_max(b.wave, self.tab_reff, self.tab_reff[0].shape[0], b.T)
+                refs['ref_C_foc'] = cqt_window_max(b.wave, self.tab_reff, p.H)
         self.refs = refs
         return b
 

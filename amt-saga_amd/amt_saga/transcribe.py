@@ -61,14 +61,18 @@ def transcribe(wf, params=None, iters=5, heads=('timing', 'pitch', 'instrument',
         loop.setup_device()
     L = p.H * (p.timing_frames - 1)
     wins, starts = cut_windows(np.asarray(wf, dtype=np.float32), L, L // 2)
-    # song-level normalisers (training.py:269-282 computes ref_mag / ref_C_* once per song): the maxima
-    # over the windows of the first batch, then shared by every window of the song
-    first = torch.from_numpy(wins[:batch]).cuda()
-    loop.prepare(first)
-    song_refs = {k: v.max() for k, v in loop.refs.items()}
+    # song-level normalisers (training.py:269-282 computes ref_mag / ref_C_* once per song, as the maximum of
+    # the song's whole STFT / CQT): the maximum over every frame of every window of the song, shared by all
+    # windows.  (A window's CQT frame equals the song's wherever the filter lies inside the window; the lowest
+    # bins of the finest grid are longer than a window and see zeros where the song continues.)
+    song_refs = None
+    for b0 in range(0, len(wins), batch):
+        loop.prepare(torch.from_numpy(wins[b0:b0 + batch]).cuda())
+        part = {k: v.max() for k, v in loop.refs.items()}
+        song_refs = part if song_refs is None else {k: torch.maximum(song_refs[k], part[k]) for k in part}
     all_ev = []
     for b0 in range(0, len(wins), batch):
-        chunk = first if b0 == 0 else torch.from_numpy(wins[b0:b0 + batch]).cuda()
+        chunk = torch.from_numpy(wins[b0:b0 + batch]).cuda()
         refs = {k: v.expand(chunk.shape[0]).contiguous() for k, v in song_refs.items()}
         e, _ = loop.run(chunk, window0=b0, refs=refs)
         all_ev.append(e.cpu().numpy())

@@ -179,6 +179,16 @@ typedef struct amt_cqt_args {
 
 int amt_cqt_slices(const amt_cqt_args *args, void *stream);
 
+/* Song-level CQT normalisers (training.py:271-282: ref_C_* = np.max(mid_wf.slice_C(0, duration,
+ * n_frames, pitch_frames, bins_per_tone=...)), the maximum of the whole CQT): out_max[b] = max over the
+ * n_bins rows of the table and over EVERY frame t = 0 .. L/hop of |C[k, t]| of window b.  O(L) per bin
+ * whatever the filter length (prefix sums of per-hop block sums); hop a power of two in 128..2048;
+ * AMT_E_UNSUPPORTED when L/hop block sums do not fit the LDS (windows beyond ~1300 hops).
+ * coef_ws = 192 * n_bins floats of device scratch (per-bin phasor table, rebuilt by every call). */
+int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_stride, int hop,
+                       const uint32_t *phase_inc, const int32_t *length, int n_bins,
+                       float *coef_ws, float *out_max, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * Loop glue: predicted note -> integer decisions, gather tables, guess pick,
  * event records.  Restates per window what training.py:296-449 does with the

@@ -96,3 +96,33 @@ def slice_C_frames(n_frames_total, s, t, target):
     t = max(s, min(t, n_frames_total))
     rel = resize_index_map(t - s, target)
     return np.where(rel < 0, -1, rel + s)
+
+
+def cqt_window_max(x, phase_inc, length, hop):
+    """max over every bin and EVERY frame t = 0 .. len(x)//hop of |C[k, t]| -- the song-level normalisers
+    ``np.max(slice_C(0, duration, n_frames, ...))`` of training.py:271-282 for the build's CQT.
+    Evaluated per bin in O(len(x)) with cumulative sums (float64): with w(n) = 1/2 - 1/2 cos(theta n),
+    sum_n x[a+n] w(n) e^{-i phi (a+n)} = 1/2 S0 - 1/4 (e^{-i theta a} S+ + e^{+i theta a} S-) over the frame's
+    support, S0 = sum z, S+- = sum z e^{+-i theta m}, z[m] = x[m] e^{-i phi m}; equal to cqt_frames() on all frames."""
+    x = np.asarray(x, dtype=np.float64)
+    L = len(x)
+    T = 1 + L // hop
+    m = np.arange(L, dtype=np.uint64)
+    best = 0.0
+    t = np.arange(T, dtype=np.int64)
+    for k in range(len(length)):
+        nk, inc = int(length[k]), int(phase_inc[k])
+        ph = ((m * np.uint64(inc)) & np.uint64(0xFFFFFFFF)).astype(np.float64) * (2.0 * np.pi / 2.0 ** 32)
+        z = x * np.exp(-1j * ph)
+        th = 2.0 * np.pi / nk
+        e = np.exp(1j * th * (np.arange(L) % nk))                  # e^{i theta m} (period nk: exact reduction)
+        c0 = np.concatenate(([0], np.cumsum(z)))
+        cp = np.concatenate(([0], np.cumsum(z * e)))
+        cm = np.concatenate(([0], np.cumsum(z * np.conj(e))))
+        a = t * hop - nk // 2
+        lo, hi = np.clip(a, 0, L), np.clip(a + nk, 0, L)
+        s0, sp, sm = c0[hi] - c0[lo], cp[hi] - cp[lo], cm[hi] - cm[lo]
+        rot = np.exp(-1j * th * (a % nk))                          # e^{-i theta a}
+        C = 0.5 * s0 - 0.25 * (rot * sp + np.conj(rot) * sm)
+        best = max(best, float(np.abs(C).max() * 2.0 / np.sqrt(nk)))
+    return best

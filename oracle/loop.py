@@ -120,25 +120,22 @@ class LoopOracle:
             events[it] = (window_id, it, pitch, program, velocity, onset, end)
         return events, ac.mag
 
-    def ref_levels(self, wave, ref_frames=8):
-        """Song-level constants as the product's prepare() defines them: ref_mag =
-        max |STFT|; ref_C_* = max of the respective CQT over `ref_frames` evenly
-        spaced frames (training.py:269-282 uses the whole song)."""
+    def ref_levels(self, wave):
+        """Song-level constants (training.py:269-282, with one window standing for the song): ref_mag =
+        max |STFT|; ref_C_* = max of the whole CQT -- every bin of the normaliser's grid, every frame."""
         p = self.p
         mag = oa.magphase(oa.stft(np.asarray(wave, np.float32), p.N, p.H))[0]
-        T = mag.shape[1]
-        frames = np.unique(np.linspace(0, T - 1, min(ref_frames, T)).round().astype(np.int32))
         f_lo = float(oa.midi_to_hz(p.pitch_low))
         span = p.pitch_high - p.pitch_low
         out = {'ref_mag': mag.max()}
         if 'pitch' in self.heads:
             t = ocqt.cqt_table(p.sr, f_lo, span, 12)
-            out['ref_C_1'] = np.float32(ocqt.cqt_frames(wave, frames, t[0], t[1], p.H).max())
+            out['ref_C_1'] = np.float32(ocqt.cqt_window_max(wave, t[0], t[1], p.H))
         if 'instrument' in self.heads:
             t = ocqt.cqt_table(p.sr, f_lo, span * p.instrument_bins_per_tone, 12 * p.instrument_bins_per_tone)
-            out['ref_C_inst'] = np.float32(ocqt.cqt_frames(wave, frames, t[0], t[1], p.H).max())
+            out['ref_C_inst'] = np.float32(ocqt.cqt_window_max(wave, t[0], t[1], p.H))
         if 'velocity' in self.heads:
             t = ocqt.cqt_table(p.sr, f_lo, span * p.instrument_bins_per_tone * 4,
                                12 * p.instrument_bins_per_tone * 4)
-            out['ref_C_foc'] = np.float32(ocqt.cqt_frames(wave, frames, t[0], t[1], p.H).max())
+            out['ref_C_foc'] = np.float32(ocqt.cqt_window_max(wave, t[0], t[1], p.H))
         return out

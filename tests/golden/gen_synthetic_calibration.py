@@ -144,10 +144,10 @@ def cqt_features(p, n, seed, kind):
             tab = ocqt.cqt_table(p.sr, float(oa.midi_to_hz(pitch - 10)), p.bins_velocity, 24)
             rt = ocqt.cqt_table(p.sr, f_lo, span * p.instrument_bins_per_tone * 4,
                                 12 * p.instrument_bins_per_tone * 4)
-        ref_frames = np.unique(np.linspace(0, T - 1, 8).round().astype(np.int32))
-        # the normaliser on a coarse sub-grid of its bins: calibration needs the scale, not the exact maximum
+        # the normaliser (max of the whole CQT) on a coarse sub-grid of its bins: calibration needs the
+        # scale, not the exact maximum
         sub = slice(None, None, max(1, len(rt[0]) // 87))
-        ref = ocqt.cqt_frames(wv, ref_frames, rt[0][sub], rt[1][sub], p.H).max()
+        ref = ocqt.cqt_window_max(wv, rt[0][sub], rt[1][sub], p.H)
         c = ocqt.cqt_frames(wv, src, tab[0], tab[1], p.H) / max(ref, 1e-12)
         if rng.random() < 0.4:
             c = c * rng.uniform(0.1, 0.7)                      # a residual after subtraction is quieter

@@ -91,11 +91,14 @@ def test_loop_32_windows_distinct_decisions(env):
     statement about 32 different functions values per head, not about a constant."""
     p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)             # 86 frames: oracle-sized
     ev, checked, skipped, lp, orc, wave_h = _run_case(env, p, ('timing', 'pitch', 'velocity'), 2, 32, seed=21)
-    assert checked >= 24, (checked, skipped)
+    # 2 iterations x (onset, end, pitch, velocity) = 8 rounded decisions per window, each within TIE of a rounding
+    # boundary with probability 2 TIE = 0.04: 1 - 0.96^8 = 28 % of the windows (9 of 32) are expected to be
+    # near-ties of the f64 oracle itself and are reported instead of compared
+    assert checked >= 20, (checked, skipped)
     assert _distinct(ev, 5) >= 10 and _distinct(ev, 6) >= 10      # onset / end frames
     assert _distinct(ev, 2) >= 10 and _distinct(ev, 4) >= 8       # pitch / velocity
     # song-level constants: the product's prepare() vs the oracle's definition
-    r0 = orc.ref_levels(wave_h[0], lp.ref_frames)
+    r0 = orc.ref_levels(wave_h[0])
     for k, v in r0.items():
         assert abs(float(lp.refs[k][0]) - v) / v < 1e-4, k
 

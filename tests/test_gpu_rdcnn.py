@@ -327,6 +327,58 @@ def test_cqt_slices(env):
             assert np.abs(out2[i] - ref).max() <= REL * max(ref.max(), 1e-6), (fmin_midi, i)
 
 
+@pytest.mark.parametrize('hop,L,grids', [
+    # N_k from 376 (< hop: no whole block) to 53938 (> L); L not a multiple of the hop
+    (512, 512 * 40 + 123, ((27.5, 87, 12), (220.0, 60, 48), (2000.0, 24, 24))),
+    # filters 30 x longer than the window (the 4 x 48 bins/octave normaliser near A0): every frame sees all samples
+    (512, 512 * 52, ((27.5, 40, 192),)),
+    (1024, 1024 * 21 + 7, ((55.0, 75, 12), (27.5, 24, 192))),
+    (256, 256 * 64 + 200, ((110.0, 48, 24),)),
+])
+def test_cqt_window_max(env, hop, L, grids):
+    """Song-level normalisers (training.py:271-282): max over every bin and EVERY frame of the window's CQT,
+    O(L)-per-bin sliding-block kernel vs the oracle's f64 cumulative-sum evaluation (itself checked against
+    the frame-by-frame definition in tests/test_oracle_torch_crosscheck.py)."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr = 44100
+    rng = np.random.default_rng(hop + L)
+    t = np.arange(L) / sr
+    waves = [np.sin(2 * np.pi * 440 * t) * np.exp(-3 * t) + 0.3 * np.sin(2 * np.pi * 1000 * t + 1),
+             0.2 * rng.standard_normal(L) * (t > 0.2),
+             np.zeros(L),                                                   # silence -> 0
+             np.sin(2 * np.pi * 61.7 * t) * 0.5 + 0.4 * (np.abs(t - 0.31) < 1e-4)]     # low tone + a click
+    wave = np.stack(waves).astype(np.float32)
+    wd = torch.from_numpy(wave).cuda()
+    for fmin, n_bins, bpo in grids:
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        got = audio.cqt_window_max(wd, table, hop).cpu().numpy()
+        for i in range(len(waves)):
+            ref = ocqt.cqt_window_max(wave[i], inc, length, hop)
+            assert abs(got[i] - ref) <= REL * ref, (fmin, n_bins, bpo, i, got[i], ref)
+        assert got[2] == 0.0
+
+
+def test_cqt_window_max_full_window(env):
+    """One 6 s window (516 frames) on the pitch head's normaliser grid: kernel vs oracle, and the maximum really is
+    attained away from the 8 sampled frames the round-1 shortcut looked at."""
+    from amt_saga import synth
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    p = env['hp'].Hyperparams(N=2048)
+    L = p.H * (p.timing_frames - 1)
+    wave = synth.make_windows(2, L, 5, (2, 4), (0,), p.sr)[0].cpu().numpy()
+    f_lo = float(audio.midi_to_hz(p.pitch_low))
+    inc, length, _ = ocqt.cqt_table(p.sr, f_lo, p.pitch_high - p.pitch_low, 12)
+    table = audio.cqt_table(p.sr, f_lo, p.pitch_high - p.pitch_low, 12, 'cuda')
+    got = audio.cqt_window_max(torch.from_numpy(wave).cuda(), table, p.H).cpu().numpy()
+    for i in range(2):
+        ref = ocqt.cqt_window_max(wave[i], inc, length, p.H)
+        assert abs(got[i] - ref) <= REL * ref, (i, got[i], ref)
+        sampled = ocqt.cqt_frames(wave[i], np.unique(np.linspace(0, p.timing_frames - 1, 8).round().astype(np.int32)),
+                                  inc, length, p.H).max()
+        assert sampled <= ref * (1 + 1e-6)
+
+
 @pytest.mark.parametrize('case', [
     dict(shape=(12, 10), k=(4, 2), pool=(2, 2), L=5, pf=2, ef=2, r=2, K=1),
     dict(shape=(9, 70), k=(4, 16), pool=(2, 8), L=4, pf=2, ef=2, r=2, K=7),

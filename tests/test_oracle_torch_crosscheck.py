@@ -212,6 +212,24 @@ def test_oracle_cqt_known_answers():
     assert C[10, 1] < 0.75 * C[10, 2]                                         # half of the first frame is padding
 
 
+def test_oracle_cqt_window_max_equals_all_frames():
+    """ref_C_* = max of the whole CQT (training.py:271-282).  oracle.cqt.cqt_window_max evaluates it in O(L) per
+    bin from cumulative sums; here it is pinned to the definition -- cqt_frames on every frame 0 .. L // hop -- for
+    filters shorter than a hop, longer than the window and 30 x longer than the window."""
+    from oracle import cqt as ocqt
+    sr, hop = 44100, 512
+    rng = np.random.default_rng(1)
+    L = hop * 40 + 123
+    t = np.arange(L) / sr
+    x = np.sin(2 * np.pi * 440 * t) * np.exp(-3 * t) + 0.3 * np.sin(2 * np.pi * 1000 * t + 1) + 0.05 * rng.standard_normal(L)
+    for fmin, n_bins, bpo in ((27.5, 87, 12), (2000.0, 24, 24), (27.5, 12, 192)):
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        brute = ocqt.cqt_frames(x, np.arange(1 + L // hop), inc, length, hop).max()
+        fast = ocqt.cqt_window_max(x, inc, length, hop)
+        assert abs(brute - fast) <= 1e-12 * brute, (fmin, brute, fast)
+    assert ocqt.cqt_window_max(np.zeros(L), inc, length, hop) == 0.0
+
+
 def test_cqt_spec_vs_librosa_like_algorithm():
     """How far is the build's CQT specification (oracle/cqt.py: direct transform, zero padding) from what
     librosa's recursive algorithm computes?  oracle/cqt_librosa_like.py restates that algorithm (octave-wise
