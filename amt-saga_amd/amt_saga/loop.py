@@ -222,5 +222,55 @@ class TranscriptionLoop:
             self.iterate(b, it, events, window0)
         return events, b
 
+    def run_stream(self, host_batches, refs=None, window0=0):
+        """run() over a sequence of HOST batches with the host -> HBM copy of batch i+1 overlapped with the
+        compute of batch i: two device staging buffers, a copy stream, and events in both directions (the
+        compute waits for its batch's copy; a copy waits until the compute that last read its buffer is done).
+        host_batches: iterable of float32 [B, L] CPU tensors or arrays (pinned memory makes the copy
+        asynchronous; pageable memory still works, serialised by the driver).  `refs`: dict of [B] device
+        tensors shared by all batches, or a callable batch_index -> dict, or None (prepare() computes them).
+        Yields (events, AudioBatch) per batch, in order; the AudioBatch's `wave` is the staging buffer and is
+        overwritten two batches later."""
+        if not self._dev_ready:
+            self.setup_device()
+        cur = torch.cuda.current_stream()
+        if getattr(self, '_copy_stream', None) is None:
+            self._copy_stream = torch.cuda.Stream()
+        cs = self._copy_stream
+        bufs = [None, None]
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        free = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def issue(i, host):
+            h = host if torch.is_tensor(host) else torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32))
+            s = i & 1
+            if bufs[s] is None or bufs[s].shape != h.shape:
+                bufs[s] = empty(tuple(h.shape))
+                cs.wait_stream(cur)                  # the allocation (and whatever freed that memory) is ordered
+            with torch.cuda.stream(cs):
+                cs.wait_event(free[s])               # no-op until the event has been recorded once
+                bufs[s].copy_(h, non_blocking=True)
+                ready[s].record(cs)
+
+        it = iter(host_batches)
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        issue(0, nxt)
+        i = 0
+        while nxt is not None:
+            nxt = next(it, None)
+            if nxt is not None:
+                issue(i + 1, nxt)                    # in flight while batch i computes
+            s = i & 1
+            cur.wait_event(ready[s])
+            r = refs(i) if callable(refs) else refs
+            events, b = self.run(bufs[s], window0=window0, refs=r)
+            free[s].record(cur)
+            window0 += bufs[s].shape[0]
+            yield events, b
+            events = b = None                        # let the allocator reuse the batch's blocks
+            i += 1
+
     def flops_per_window_iter(self):
         return sum(n.flops_per_window for n in self.nets.values())

@@ -22,6 +22,8 @@ Prints ONE JSON line on rank 0 with the driver contract plus
   value_f32_mfma          the same step with the strict-f32 convolutions (--conv-mode 0), same run
   value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
                           (SURVEY 8d defines the metric including that copy; never `value`)
+  value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
+                          (TranscriptionLoop.run_stream), steady state
   prepare_ms              the untimed per-batch set-up (STFT + song-level CQT normalisers)
 """
 import argparse
@@ -367,6 +369,22 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); stage.copy_(host, non_blocking=True); e1.record(); torch.cuda.synchronize()
         extras['h2d_gbs'] = round(B * L * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        # (3) the same with the copy of batch i+1 overlapped with the compute of batch i
+        # (TranscriptionLoop.run_stream: copy stream + two staging buffers); steady state: the first batch's
+        # copy is issued before the clock starts, k1 copies and k1 computes lie inside it
+        gen = loop.run_stream((host for _ in range(k1 + 2)), refs=refs, window0=rank * B)
+        next(gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k1):
+            ev_s, _b = next(gen)
+            adist.gather_events(ev_s.reshape(-1, 7), n_total=B * world * wl['iters'])
+            ev_s = _b = None
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        gen.close()
+        torch.cuda.synchronize()
+        extras['value_h2d_overlapped'] = round(B * world * k1 / dt2, 2)
         del host, stage
 
     cpu = None

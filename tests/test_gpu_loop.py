@@ -175,3 +175,25 @@ def test_loop_properties_full_size(env):
     sub = {k: v[2:5].contiguous() for k, v in refs.items()}
     ev3, _ = lp.run(wave[2:5].contiguous(), window0=2, refs=sub)
     assert np.array_equal(ev3.cpu().numpy(), e[:, 2:5, :])
+
+
+def test_run_stream_overlapped_copy_equals_run(env):
+    """TranscriptionLoop.run_stream (host batches, copy of batch i+1 on a second stream under the compute of
+    batch i, two staging buffers) yields bit-identical events to run() on device-resident copies of the same
+    batches -- including a ragged last batch and pageable (unpinned) host memory."""
+    torch, synth = env['torch'], env['synth']
+    p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
+    lp = env['loop'].TranscriptionLoop(p, heads=('timing', 'pitch', 'velocity'), iters=2).setup_device()
+    L = p.H * (p.timing_frames - 1)
+    sizes = (6, 6, 6, 6, 3)
+    waves = [synth.make_windows(n, L, seed=40 + i, notes_per_window=(1, 3), device='cuda')[0] for i, n in enumerate(sizes)]
+    want, w0 = [], 7
+    for w in waves:
+        want.append(lp.run(w, window0=w0)[0].cpu().numpy())
+        w0 += w.shape[0]
+    hosts = [w.cpu().pin_memory() if i % 2 == 0 else w.cpu().numpy() for i, w in enumerate(waves)]
+    got = [e.cpu().numpy() for e, _ in lp.run_stream(hosts, window0=7)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert list(lp.run_stream([])) == []
