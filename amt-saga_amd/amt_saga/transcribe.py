@@ -70,12 +70,12 @@ def transcribe(wf, params=None, iters=5, heads=('timing', 'pitch', 'instrument',
         loop.prepare(torch.from_numpy(wins[b0:b0 + batch]).cuda())
         part = {k: v.max() for k, v in loop.refs.items()}
         song_refs = part if song_refs is None else {k: torch.maximum(song_refs[k], part[k]) for k in part}
-    all_ev = []
-    for b0 in range(0, len(wins), batch):
-        chunk = torch.from_numpy(wins[b0:b0 + batch]).cuda()
-        refs = {k: v.expand(chunk.shape[0]).contiguous() for k, v in song_refs.items()}
-        e, _ = loop.run(chunk, window0=b0, refs=refs)
-        all_ev.append(e.cpu().numpy())
+    # the loop proper: host batches streamed through run_stream (copy of batch i+1 under the compute of batch i)
+    chunks = [wins[b0:b0 + batch] for b0 in range(0, len(wins), batch)]
+
+    def refs_for(i):
+        return {k: v.expand(len(chunks[i])).contiguous() for k, v in song_refs.items()}
+    all_ev = [e.cpu().numpy() for e, _ in loop.run_stream(chunks, refs=refs_for)]
     evs = np.concatenate(all_ev, axis=1)
     notes = ev.events_to_notes(evs, p.timing_frames, L, sr=p.sr,
                                window_start_s=[s / p.sr for s in starts])

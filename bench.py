@@ -57,6 +57,7 @@ WORKLOADS = {
                name='C5 shard: 2048 mixed-instrument windows per GPU, all heads, 5 iterations'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SUSTAINED_F16_TF = 1620.0     # measured: scripts/probes/mfma_peak.hip, random operands, 2-4 waves per SIMD
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense FP32 matrix peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense BF16 matrix peak
 
@@ -309,6 +310,11 @@ def main():
                     peak_note=('dense bf16/f16 MFMA peak 2500 / %d MFMAs per f32-equivalent product block' % nmf
                                if split else 'dense f32 MFMA peak'),
                     executed_mfma_tflops=round(achieved_tf * (nmf if split else 1), 1),
+                    # scripts/probes/mfma_peak.hip on this chip (profiles/r02/mfma_sustained_probe.txt): back-to-back
+                    # v_mfma_f32_16x16x32_f16 on register operands, nothing else running, sustains 1620 TFLOP/s on
+                    # random non-zero data (2090 on zeros): the power limit, not the schedule, sets the f16 ceiling
+                    **({'sustained_f16_mfma_tflops_measured': SUSTAINED_F16_TF,
+                        'executed_vs_sustained': round(achieved_tf * nmf / SUSTAINED_F16_TF, 3)} if split else {}),
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2))

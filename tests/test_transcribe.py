@@ -41,6 +41,10 @@ def test_transcribe_flac_to_midi(tmp_path):
     assert np.array_equal(evs[0, :, 0], np.arange(n_win))       # window ids follow the song order
     assert all(21 <= e['pitch'] <= 108 and e['end'] > e['start'] >= 0 for e in notes)
     assert len(notes) <= 2 * n_win
+    # the same song in batches of 3 windows (song-level normalisers over all batches, batches streamed with the
+    # copy overlapped): the events do not depend on how the windows are batched
+    notes_b, evs_b = tr.transcribe(back, p, iters=2, heads=('timing', 'pitch', 'instrument', 'velocity'), batch=3)
+    assert np.array_equal(evs_b, evs) and notes_b == notes
     mid = str(tmp_path / 'out.mid')
     events.write_midi(notes, mid)
     rd = events.read_midi(mid)
