@@ -31,7 +31,7 @@ class SubtractArgs(C.Structure):
 
 class CqtArgs(C.Structure):
     _fields_ = [('wave', vp), ('src_frame', vp), ('bin0', vp), ('phase_inc', vp),
-                ('length', vp), ('ref', vp), ('out', vp), ('wave_stride', C.c_size_t),
+                ('length', vp), ('ref', vp), ('coef', vp), ('out', vp), ('wave_stride', C.c_size_t),
                 ('B', C.c_int32), ('L', C.c_int32), ('hop', C.c_int32), ('frames', C.c_int32),
                 ('n_bins', C.c_int32), ('n_table', C.c_int32)]
 
@@ -72,7 +72,8 @@ PROTOTYPES = {
     'amt_db_to_amplitude': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
     'amt_spectral_flatness': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float, vp, vp]),
     'amt_cqt_slices': (C.c_int, [C.POINTER(CqtArgs), vp]),
-    'amt_cqt_window_max': (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, C.c_int, vp, vp, vp]),
+    'amt_cqt_coef': (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    'amt_cqt_window_max': (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
     'amt_round_clamp': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'amt_argmax_rows': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     'amt_resize_table': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

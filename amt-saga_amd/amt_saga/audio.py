@@ -255,8 +255,8 @@ def db_to_amplitude(db, ref, F):
 
 def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     """slice_C for a batch (util_audio.py:411-434, build-defined CQT):
-    wave [B, L] f32 device; src_frame [B, frames] int32; table = (phase_inc uint32
-    tensor, length int32 tensor).  Returns [B, n_bins, frames]."""
+    wave [B, L] f32 device; src_frame [B, frames] int32; table = cqt_table(..., device) =
+    (phase_inc, length, coef).  Returns [B, n_bins, frames]."""
     lib = _lib.load()
     B, L = wave.shape
     frames = src_frame.shape[1]
@@ -268,6 +268,7 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     a.phase_inc = table[0].data_ptr()
     a.length = table[1].data_ptr()
     a.ref = ref.data_ptr() if ref is not None else None
+    a.coef = table[2].data_ptr()
     a.out = out.data_ptr()
     a.wave_stride = _stride0(wave)
     a.B, a.L, a.hop, a.frames, a.n_bins, a.n_table = B, L, int(hop), frames, int(n_bins), \
@@ -283,10 +284,8 @@ def cqt_window_max(wave, table, hop):
     lib = _lib.load()
     B, L = wave.shape
     out = empty((B,))
-    n_bins = int(table[0].shape[0])
-    coef = empty((n_bins, 192))
     _lib.check(lib.amt_cqt_window_max(ptr(wave), B, L, _stride0(wave), int(hop), ptr(table[0]), ptr(table[1]),
-                                      n_bins, ptr(coef), ptr(out), stream_ptr()))
+                                      ptr(table[2]), int(table[0].shape[0]), ptr(out), stream_ptr()))
     return out
 
 
@@ -303,7 +302,12 @@ def cqt_table(sr, fmin_hz, n_bins, bins_per_octave, device=None):
     inc = (np.rint(freq / sr * 2.0 ** 32).astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     if device is None:
         return inc, length
-    return (torch.from_numpy(inc.view(np.int32)).to(device), torch.from_numpy(length).to(device))
+    # device form: (phase_inc, length, coef) -- coef = the per-bin phasor table the CQT kernels read through the
+    # scalar cache (amt_cqt_coef), built once here
+    inc_d, len_d = torch.from_numpy(inc.view(np.int32)).to(device), torch.from_numpy(length).to(device)
+    coef = empty((int(n_bins), 192))
+    _lib.check(_lib.load().amt_cqt_coef(ptr(inc_d), ptr(len_d), int(n_bins), ptr(coef), stream_ptr()))
+    return (inc_d, len_d, coef)
 
 
 _NOTE = {'C': 0, 'D': 2, 'E': 4, 'F': 5, 'G': 7, 'A': 9, 'B': 11}

@@ -1,241 +1,26 @@
-// Constant-Q slices at the (<= 8) frames the heads keep, for gfx950.
+// Constant-Q transform of the build's own spec (oracle/cqt.py) for gfx950: the <= 8 frames a head keeps
+// (slice_C, /root/reference/util_audio.py:411-434: |librosa.cqt| then _resize(C[:, s:t], target)) and the
+// maximum of the whole transform (the song-level normalisers of training.py:271-282).
 //
-// Stands where audio_complete.slice_C calls |librosa.cqt| and keeps
-// _resize(C[:, s:t], target) (/root/reference/util_audio.py:411-434).  The
-// transform is the build's own spec (oracle/cqt.py): direct constant-Q
-// response with periodic-Hann, L1-normalised filters of length N_k, scaled by
-// sqrt(N_k); frequencies quantised to uint32 cycles/sample so the oscillator
-// phase is exact integer arithmetic on CPU and GPU alike.
-//
-// One workgroup per (window, bin).  With w(n) = 1/2 - 1/2 cos(theta n), theta = 2 pi / N_k,
-// a frame that starts o hops after the first one is
-//     C_o = 1/2 S0 - 1/4 ( e^{-i theta o H} S+  +  e^{+i theta o H} S- )
-//     S0 = sum x[m] e^{-i phi m},  S+- = sum x[m] e^{-i phi m} e^{+-i theta u},  u = m - a_min
-// summed over the frame's support.  The frames of a slice start whole hops apart, so their
-// supports are the same run of H-sample blocks shifted by o: the blocks every frame shares
-// (the "core") are accumulated once in registers -- one oscillator sincos, one window sincos
-// and a dozen FMAs per sample, independent of the number of frames -- and only the <= 7 head
-// / <= 8 tail blocks (plus the N_k mod H prefix of the block behind each frame) are kept as
-// per-block sums in LDS and combined per frame at the end.  Frame sets wider than 8 hops
-// (the song-level normalisers sample the whole window) take the generic path: every frame's
-// Hann weight per sample via the angle-sum identity.  VALU/L2-bound; no MFMA.
+// The transform: direct constant-Q response with periodic-Hann, L1-normalised filters of length N_k, scaled by
+// sqrt(N_k); frequencies quantised to uint32 cycles/sample so the oscillator phase is exact integer
+// arithmetic on CPU and GPU alike.  With w(n) = 1/2 - 1/2 cos(theta n), theta = 2 pi / N_k, a frame that
+// starts at sample s is
+//     C = 1/2 S0 - 1/4 ( e^{-i theta (s + N_k/2)} S+  +  e^{+i theta (s + N_k/2)} S- ),
+//     S0 = sum x[m] e^{-i phi m},  S+- = sum x[m] e^{-i phi m} e^{+-i theta u},  u = m + N_k/2
+// summed over the frame's support; frames start whole hops apart, so their supports are runs of the same
+// H-sample blocks and every frame is a difference of two prefix sums of block sums plus one block head.
+// VALU / L1-bound; no MFMA.
 #include "amt_common.h"
 
 #define AMT_CQT_MAXF 8
-#define CQ_EDGE 16                      // head blocks 0..6 -> 0..6, tail blocks nb+i -> 7+i (i <= 8)
-
-struct c3 { float r0, i0, rp, ip, rm, im; };
-
-__device__ __forceinline__ void cq_accum(c3 &s, float xv, float c, float sn, float cw, float sw) {
-    // z = x e^{-i phi} = (xv c, -xv sn).  S+- = sum z e^{+-i theta u} = P +- iQ with the cosine- and
-    // sine-weighted sums P = sum z cos(theta u), Q = sum z sin(theta u): four multiply-adds per
-    // sample instead of eight; (rp, ip) holds P and (rm, im) holds Q until cq_finish().
-    const float zr = xv * c, zi = -xv * sn;
-    s.r0 += zr; s.i0 += zi;
-    s.rp += zr * cw; s.ip += zi * cw;
-    s.rm += zr * sw; s.im += zi * sw;
-}
-__device__ __forceinline__ void cq_finish(c3 &s) {        // (P, Q) -> (S+, S-)
-    const float pr = s.rp, pi_ = s.ip, qr = s.rm, qi = s.im;
-    s.rp = pr - qi; s.ip = pi_ + qr;                       // S+ = P + iQ
-    s.rm = pr + qi; s.im = pi_ - qr;                       // S- = P - iQ
-}
-__device__ __forceinline__ void cq_wave_sum(c3 &s) {
-    s.r0 = wave_sum(s.r0); s.i0 = wave_sum(s.i0); s.rp = wave_sum(s.rp);
-    s.ip = wave_sum(s.ip); s.rm = wave_sum(s.rm); s.im = wave_sum(s.im);
-}
-__device__ __forceinline__ void cq_add(c3 &s, const c3 &t) {
-    s.r0 += t.r0; s.i0 += t.i0; s.rp += t.rp; s.ip += t.ip; s.rm += t.rm; s.im += t.im;
-}
-
-__global__ __launch_bounds__(256) void cqt_slices_kernel(amt_cqt_args a) {
-    __shared__ float red[4][2 * AMT_CQT_MAXF];
-    __shared__ c3 edgeP[CQ_EDGE], edgeQ[CQ_EDGE], coreS[4];
-    const int k = blockIdx.x;                       // output bin
-    const int b = blockIdx.y;
-    const int kt = (a.bin0 ? a.bin0[b] : 0) + k;    // table row
-    const int tid = threadIdx.x;
-    float *o = a.out + ((size_t)b * a.n_bins + k) * a.frames;
-    if (kt < 0 || kt >= a.n_table) {                // uniform; outside the table -> zeros
-        if (tid < a.frames) o[tid] = 0.f;
-        return;
-    }
-    const int nk = a.length[kt];
-    const unsigned int inc = a.phase_inc[kt];
-    const float *x = a.wave + (size_t)b * a.wave_stride;
-    const int half = nk >> 1;
-    const int H = a.hop;
-    const int wid = tid >> 6, lane = tid & 63;
-
-    int start[AMT_CQT_MAXF];
-    int a_min = 0x7fffffff, a_max = -0x7fffffff;
-    bool have = false;
-#pragma unroll
-    for (int j = 0; j < AMT_CQT_MAXF; ++j) {
-        const int t = j < a.frames ? a.src_frame[b * a.frames + j] : -1;
-        if (t < 0) { start[j] = 0x40000000; continue; }
-        start[j] = t * H - half;
-        have = true;
-        a_min = min(a_min, start[j]);
-        a_max = max(a_max, start[j]);
-    }
-    if (!have) { if (tid < a.frames) o[tid] = 0.f; return; }
-    const float inv_nk = 1.0f / (float)nk;
-    const float scale = 2.0f / sqrtf((float)nk);
-
-    if (a_max - a_min <= 7 * H) {
-        // ------------------------------ compact frame set -------------------------------
-        const int nb = nk / H;                       // full blocks per frame
-        const int rpre = nk - nb * H;                // prefix of the block behind a frame
-        const int omax = (a_max - a_min) / H;
-        const int nblk = omax + nb + 1;              // blocks 0 .. omax+nb
-        if (tid < CQ_EDGE) { edgeP[tid] = c3{0, 0, 0, 0, 0, 0}; edgeQ[tid] = c3{0, 0, 0, 0, 0, 0}; }
-        __syncthreads();
-        c3 core{0, 0, 0, 0, 0, 0};
-        for (int blk = wid; blk < nblk; blk += 4) {  // one wave per H-sample block
-            const bool edge = blk < 7 || blk >= nb;  // wave-uniform
-            c3 p{0, 0, 0, 0, 0, 0}, q{0, 0, 0, 0, 0, 0};
-            const int mb = a_min + blk * H;                      // first sample of the block
-            if (!edge && mb >= 0 && mb + H <= a.L) {
-                // interior core block (the bulk of the work): no per-sample bounds test, no branches
-                const float *xb = x + mb;
-                auto body = [&](int i) {
-                    const float xv = xb[i];
-                    const float turns = (float)((unsigned int)(mb + i) * inc) * 2.3283064365386963e-10f;
-                    const float sn = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
-                    const float wt = (float)(blk * H + i) * inv_nk;
-                    const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
-                    cq_accum(core, xv, c, sn, cw, sw);
-                };
-                if (H == 512) {                                  // the hop of the N = 2048 path: fully unrolled
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) body(lane + 64 * j);
-                } else {
-                    for (int i = lane; i < H; i += 64) body(i);
-                }
-                continue;
-            }
-            for (int i = lane; i < H; i += 64) {
-                const int u = blk * H + i;
-                const int m = a_min + u;
-                const float xv = (m >= 0 && m < a.L) ? x[m] : 0.f;
-                // v_sin_f32 / v_cos_f32 take their argument in turns (1.0 = 2 pi), |x| <= 256
-                const float turns = (float)((unsigned int)m * inc) * 2.3283064365386963e-10f;
-                const float sn = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
-                const float wt = (float)u * inv_nk;
-                const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
-                if (edge) {
-                    cq_accum(p, xv, c, sn, cw, sw);
-                    if (i < rpre) cq_accum(q, xv, c, sn, cw, sw);
-                } else {
-                    cq_accum(core, xv, c, sn, cw, sw);
-                }
-            }
-            if (edge) {
-                const int e = blk < 7 ? blk : 7 + (blk - nb);
-                cq_wave_sum(p);
-                cq_wave_sum(q);
-                if (lane == 0 && e < CQ_EDGE) { edgeP[e] = p; edgeQ[e] = q; }
-            }
-        }
-        cq_wave_sum(core);
-        if (lane == 0) coreS[wid] = core;
-        __syncthreads();
-        if (tid < a.frames) {
-            float v = 0.f;
-            const int st = a.src_frame[b * a.frames + tid];
-            if (st >= 0) {
-                const int oj = (st * H - half - a_min) / H;
-                c3 s{0, 0, 0, 0, 0, 0};
-                cq_add(s, coreS[0]); cq_add(s, coreS[1]); cq_add(s, coreS[2]); cq_add(s, coreS[3]);
-                for (int blk = oj; blk < oj + nb; ++blk)
-                    if (blk < 7 || blk >= nb) cq_add(s, edgeP[blk < 7 ? blk : 7 + (blk - nb)]);
-                {
-                    const int blk = oj + nb;         // the block behind the frame: its N_k mod H prefix
-                    cq_add(s, edgeQ[blk < 7 ? blk : 7 + (blk - nb)]);
-                }
-                cq_finish(s);
-                // C = 1/2 S0 - 1/4 (e^{-i theta o H} S+ + e^{+i theta o H} S-)
-                float sd, cd;
-                sincospif(2.0f * (float)(oj * H) * inv_nk, &sd, &cd);
-                const float pr = cd * s.rp + sd * s.ip, pi_ = cd * s.ip - sd * s.rp;   // e^{-i d} S+
-                const float mr = cd * s.rm - sd * s.im, mi = cd * s.im + sd * s.rm;   // e^{+i d} S-
-                const float re = 0.5f * s.r0 - 0.25f * (pr + mr);
-                const float im = 0.5f * s.i0 - 0.25f * (pi_ + mi);
-                v = sqrtf(re * re + im * im) * scale;
-                if (a.ref) v = __fdiv_rn(v, a.ref[b]);
-            }
-            o[tid] = v;
-        }
-        return;
-    }
-
-    // ------------------------------ generic frame set -----------------------------------
-    float cd[AMT_CQT_MAXF], sd[AMT_CQT_MAXF];
-    const int a0 = a_min;
-    int m_lo = a_min, m_hi = a_max + nk;
-#pragma unroll
-    for (int j = 0; j < AMT_CQT_MAXF; ++j) {
-        // cos(theta*(u - d)) = cos(theta u) cos(theta d) + sin(theta u) sin(theta d),
-        // u = m - a0, d = start[j] - a0, theta = 2 pi / N_k   (angles in half-turns)
-        const float d = (float)(start[j] - a0);
-        sincospif(2.0f * d * inv_nk, &sd[j], &cd[j]);
-        if (start[j] == 0x40000000) { cd[j] = 0.f; sd[j] = 0.f; }
-    }
-    m_lo = max(m_lo, 0);
-    m_hi = min(m_hi, a.L);
-    float re[AMT_CQT_MAXF], im[AMT_CQT_MAXF];
-#pragma unroll
-    for (int j = 0; j < AMT_CQT_MAXF; ++j) { re[j] = 0.f; im[j] = 0.f; }
-    for (int m = m_lo + tid; m < m_hi; m += 256) {
-        const float xv = x[m];
-        const float turns = (float)((unsigned int)m * inc) * 2.3283064365386963e-10f;
-        const float s = __builtin_amdgcn_sinf(turns), c = __builtin_amdgcn_cosf(turns);
-        const float xr = xv * c, xi = -xv * s;                          // x * exp(-i phi)
-        const float wt = (float)(m - a0) * inv_nk;
-        const float sw = __builtin_amdgcn_sinf(wt), cw = __builtin_amdgcn_cosf(wt);
-#pragma unroll
-        for (int j = 0; j < AMT_CQT_MAXF; ++j) {
-            const int n = m - start[j];
-            float w = 0.5f - 0.5f * (cw * cd[j] + sw * sd[j]);
-            w = (n >= 0 && n < nk) ? w : 0.f;
-            re[j] += xr * w;
-            im[j] += xi * w;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < AMT_CQT_MAXF; ++j) {
-        const float r = wave_sum(re[j]), i = wave_sum(im[j]);
-        if (lane == 0) { red[wid][2 * j] = r; red[wid][2 * j + 1] = i; }
-    }
-    __syncthreads();
-    if (tid < a.frames) {
-        const float r = red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid];
-        const float i = red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1];
-        float v = sqrtf(r * r + i * i) * scale;
-        if (a.ref) v = __fdiv_rn(v, a.ref[b]);
-        if (a.src_frame[b * a.frames + tid] < 0) v = 0.f;
-        o[tid] = v;
-    }
-}
-
-extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
-    if (!args || !args->wave || !args->src_frame || !args->phase_inc || !args->length || !args->out)
-        return AMT_E_INVALID;
-    const amt_cqt_args &a = *args;
-    if (a.B <= 0 || a.L <= 0 || a.hop <= 0 || a.n_bins <= 0 || a.n_table <= 0) return AMT_E_INVALID;
-    if (a.frames <= 0 || a.frames > AMT_CQT_MAXF) return AMT_E_UNSUPPORTED;
-    if (a.wave_stride < (size_t)a.L) return AMT_E_SHAPE;
-    cqt_slices_kernel<<<dim3(a.n_bins, a.B), 256, 0, (hipStream_t)stream>>>(a);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
-}
 
 // ---------------------------------------------------------------------------------------------
-// Song-level normalisers: max over every bin and EVERY frame of a window's CQT
-// (np.max(mid_wf.slice_C(0, duration, n_frames, ...)), /root/reference/training.py:271-282).
+// One kernel, two uses: the maximum over every bin and EVERY frame of a window's CQT (song-level
+// normalisers, np.max(mid_wf.slice_C(0, duration, n_frames, ...)), training.py:271-282) and the <= 8
+// frames of a slice (slice_C).
 //
-// One workgroup per (bin, window); the cost per bin is O(L) whatever N_k is.  With block j =
+// One workgroup per (bin, window); the cost per bin is O(samples under the requested frames) whatever N_k is.  With block j =
 // samples [jH - N_k/2, (j+1)H - N_k/2) (frame t starts at block t), the per-block sums
 //     F_j = sum over the block,  G_j = sum over its first N_k mod H samples
 // of (z, z e^{+i theta u}, z e^{-i theta u}), z = x[m] e^{-i phi m}, u = m + N_k/2, give every frame as
@@ -295,28 +80,61 @@ __device__ __forceinline__ void cm_group(const float *xs, const amt_v2 *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void cqt_window_max_kernel(const float *__restrict__ wave, int L, size_t wave_stride,
-                                                             int H, int hshift, int T,
-                                                             const unsigned int *__restrict__ phase_inc,
-                                                             const int *__restrict__ length,
-                                                             const float *__restrict__ coef, int blk_cap,
-                                                             unsigned int *__restrict__ out) {
+struct CqtBlocksArgs {
+    size_t wave_stride;
+    int L, H, hshift, T;
+    int blk_cap;
+    unsigned int *out_max;      // max mode: [B] float bits, zeroed by the caller
+    const int *src_frame;       // slices mode: [B][frames], -1 => zero column
+    const int *bin0;            // slices mode: [B] first table row of the window, or null
+    const float *ref;           // slices mode: [B] divisor or null
+    float *out;                 // slices mode: [B][n_bins][frames]
+    int frames, n_bins, n_table;
+};
+
+// SLICES = false: every frame 0 .. T-1, maximum over frames -> atomicMax(out_max[b])   (amt_cqt_window_max)
+// SLICES = true:  the <= 8 frames src_frame[b][*] -> out[b][k][*] / ref[b]              (amt_cqt_slices); only the
+//                 blocks those frames touch are summed
+// (the read-only arrays are separate __restrict__ parameters: as struct members the table reads lose the
+// no-alias guarantee and stop being scalar loads)
+template <bool SLICES>
+__global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict__ wave,
+                                                         const unsigned int *__restrict__ phase_inc,
+                                                         const int *__restrict__ length,
+                                                         const float *__restrict__ coef, CqtBlocksArgs a) {
     extern __shared__ double cm_smem[];
     float *stage = (float *)cm_smem;                 // [4][CM_STAGE]; the epilogue reuses it for PF
     double *pf = cm_smem;                            // [nblk + 1][6]
-    float *fg = stage + max(4 * CM_STAGE, (blk_cap + 1) * 12);          // [blk_cap][12]  (F_j, G_j)
+    float *fg = stage + max(4 * CM_STAGE, (a.blk_cap + 1) * 12);        // [blk_cap][12]  (F_j, G_j)
     const int k = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const int nk = __builtin_amdgcn_readfirstlane(length[k]);
-    const unsigned int inc = __builtin_amdgcn_readfirstlane(phase_inc[k]);
-    const amt_v2 *__restrict__ cf = (const amt_v2 *)(coef + (size_t)k * CM_COEF);
-    const float *x = wave + (size_t)b * wave_stride;
+    const int L = a.L, H = a.H, hshift = a.hshift, T = a.T;
+    int kt = k, t_min = 0, t_max = T - 1;
+    if (SLICES) {
+        kt += a.bin0 ? __builtin_amdgcn_readfirstlane(a.bin0[b]) : 0;
+        t_min = 0x7fffffff; t_max = -1;
+        for (int j = 0; j < a.frames; ++j) {
+            const int t = a.src_frame[b * a.frames + j];
+            if (t >= 0) { t_min = min(t_min, t); t_max = max(t_max, t); }
+        }
+        if (kt < 0 || kt >= a.n_table || t_max < 0) {       // uniform: outside the table / an empty slice -> zeros
+            if (tid < a.frames) a.out[((size_t)b * a.n_bins + k) * a.frames + tid] = 0.f;
+            return;
+        }
+        t_min = __builtin_amdgcn_readfirstlane(t_min);
+        t_max = __builtin_amdgcn_readfirstlane(t_max);
+    }
+    const int nk = __builtin_amdgcn_readfirstlane(length[kt]);
+    const unsigned int inc = __builtin_amdgcn_readfirstlane(phase_inc[kt]);
+    const amt_v2 *__restrict__ cf = (const amt_v2 *)(coef + (size_t)kt * CM_COEF);
+    const float *x = wave + (size_t)b * a.wave_stride;
     const int half = nk >> 1;
     const int nb = nk >> hshift, rpre = nk - (nb << hshift);
     const int LPB = H >> 5;                          // lanes per block
     const int BPW = 64 / LPB, NBP = 4 * BPW;         // blocks per wave / per pass of the workgroup
-    const int j_lo = half >> hshift, j_hi = (L - 1 + half) >> hshift;    // blocks that hold samples
-    const int nblk = j_hi - j_lo + 1;                // <= blk_cap
+    // blocks that hold samples AND lie under a requested frame (frame t = blocks t .. t+nb)
+    const int j_lo = max(half >> hshift, t_min), j_hi = min((L - 1 + half) >> hshift, t_max + nb);
+    const int nblk = max(j_hi - j_lo + 1, 0);        // <= blk_cap
     const float inv_nk = 1.0f / (float)nk;
     const int r32 = rpre & 31, qcut = rpre >> 5;     // G_j = segments < qcut whole + the first r32 samples of segment qcut
     const int gq = r32 >> 3, r8 = r32 & 7;
@@ -346,7 +164,7 @@ __global__ __launch_bounds__(256) void cqt_window_max_kernel(const float *__rest
             }
         }
     };
-    fetch(0);
+    if (n_pass > 0) fetch(0);
     int wrem = ((j_lo << hshift) + (wid * BPW << hshift) + lane * 32) % nk;     // (ms + N_k/2) mod N_k, kept incrementally
     const int wstep = (NBP << hshift) % nk;
     for (int c = 0; c < n_pass; ++c) {
@@ -444,9 +262,8 @@ __global__ __launch_bounds__(256) void cqt_window_max_kernel(const float *__rest
         }
     }
     __syncthreads();
-    float vmax = 0.f;
     const float scale = 2.0f / sqrtf((float)nk);
-    for (int t = tid; t < T; t += 256) {             // frame t: blocks t .. t+nb-1 whole, the head of block t+nb
+    auto frame = [&](int t) -> float {               // frame t: blocks t .. t+nb-1 whole, the head of block t+nb
         const int i0 = min(max(t - j_lo, 0), nblk), i1 = min(max(t + nb - j_lo, 0), nblk);
         const int jg = t + nb - j_lo;
         float sfr[6];
@@ -461,38 +278,88 @@ __global__ __launch_bounds__(256) void cqt_window_max_kernel(const float *__rest
         const float br = cd * sfr[4] - sd * sfr[5], bi = cd * sfr[5] + sd * sfr[4];     // e^{+i d} S-
         const float re = 0.5f * sfr[0] - 0.25f * (ar + br);
         const float im = 0.5f * sfr[1] - 0.25f * (ai + bi);
-        vmax = fmaxf(vmax, sqrtf(re * re + im * im) * scale);
+        return sqrtf(re * re + im * im) * scale;
+    };
+    if (SLICES) {
+        if (tid < a.frames) {
+            const int t = a.src_frame[b * a.frames + tid];
+            float v = t >= 0 ? frame(t) : 0.f;
+            if (a.ref) v = __fdiv_rn(v, a.ref[b]);
+            a.out[((size_t)b * a.n_bins + k) * a.frames + tid] = v;
+        }
+        return;
     }
+    float vmax = 0.f;
+    for (int t = tid; t < T; t += 256) vmax = fmaxf(vmax, frame(t));
     vmax = wave_max(vmax);
-    if (lane == 0) atomicMax(out + b, __float_as_uint(vmax));         // non-negative floats order as their bits
+    if (lane == 0) atomicMax(a.out_max + b, __float_as_uint(vmax));   // non-negative floats order as their bits
+}
+
+static int cqt_blocks_geometry(int L, int hop, int *hshift, int *blk_cap, size_t *lds) {
+    if (!amt_is_pow2(hop) || hop < 128 || hop > 2048) return AMT_E_UNSUPPORTED;
+    *hshift = 0;
+    while ((1 << *hshift) < hop) ++*hshift;
+    *blk_cap = L / hop + 3;                          // blocks that can hold samples, whatever the filter length
+    const size_t stage_floats = (size_t)4 * CM_STAGE > (size_t)(*blk_cap + 1) * 12 ? (size_t)4 * CM_STAGE
+                                                                                    : (size_t)(*blk_cap + 1) * 12;
+    *lds = (stage_floats + (size_t)*blk_cap * 12) * sizeof(float);
+    return *lds > 159 * 1024 ? AMT_E_UNSUPPORTED : AMT_OK;
+}
+
+extern "C" int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, int n_table, float *coef, void *stream) {
+    if (!phase_inc || !length || !coef || n_table <= 0) return AMT_E_INVALID;
+    cqt_coef_kernel<<<(n_table * 32 + 255) / 256, 256, 0, (hipStream_t)stream>>>(phase_inc, length, n_table, coef);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
+    if (!args || !args->wave || !args->src_frame || !args->phase_inc || !args->length || !args->coef || !args->out)
+        return AMT_E_INVALID;
+    const amt_cqt_args &q = *args;
+    if (q.B <= 0 || q.L <= 0 || q.hop <= 0 || q.n_bins <= 0 || q.n_table <= 0) return AMT_E_INVALID;
+    if (q.frames <= 0 || q.frames > AMT_CQT_MAXF) return AMT_E_UNSUPPORTED;
+    if (q.wave_stride < (size_t)q.L) return AMT_E_SHAPE;
+    CqtBlocksArgs a{};
+    size_t lds;
+    const int rc = cqt_blocks_geometry(q.L, q.hop, &a.hshift, &a.blk_cap, &lds);
+    if (rc != AMT_OK) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    a.wave_stride = q.wave_stride; a.L = q.L; a.H = q.hop; a.T = 1 + q.L / q.hop;
+    a.src_frame = q.src_frame; a.bin0 = q.bin0; a.ref = q.ref; a.out = q.out;
+    a.frames = q.frames; a.n_bins = q.n_bins; a.n_table = q.n_table;
+    cqt_blocks_kernel<true><<<dim3(q.n_bins, q.B), 256, lds, (hipStream_t)stream>>>(q.wave, q.phase_inc, q.length,
+                                                                                     q.coef, a);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
 }
 
 extern "C" int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_stride, int hop,
-                                  const uint32_t *phase_inc, const int32_t *length, int n_bins,
-                                  float *coef_ws, float *out_max, void *stream) {
-    if (!wave || !phase_inc || !length || !coef_ws || !out_max) return AMT_E_INVALID;
+                                  const uint32_t *phase_inc, const int32_t *length, const float *coef, int n_bins,
+                                  float *out_max, void *stream) {
+    if (!wave || !phase_inc || !length || !coef || !out_max) return AMT_E_INVALID;
     if (B <= 0 || L <= 0 || n_bins <= 0) return AMT_E_INVALID;
     if (wave_stride < (size_t)L) return AMT_E_SHAPE;
-    if (!amt_is_pow2(hop) || hop < 128 || hop > 2048) return AMT_E_UNSUPPORTED;
-    int hshift = 0;
-    while ((1 << hshift) < hop) ++hshift;
-    const int blk_cap = L / hop + 3;                 // blocks that can hold samples, whatever the filter length
-    const size_t stage_floats = (size_t)4 * CM_STAGE > (size_t)(blk_cap + 1) * 12 ? (size_t)4 * CM_STAGE
-                                                                                   : (size_t)(blk_cap + 1) * 12;
-    const size_t lds = (stage_floats + (size_t)blk_cap * 12) * sizeof(float);
-    if (lds > 159 * 1024) return AMT_E_UNSUPPORTED;
+    CqtBlocksArgs a{};
+    size_t lds;
+    const int rc = cqt_blocks_geometry(L, hop, &a.hshift, &a.blk_cap, &lds);
+    if (rc != AMT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_window_max_kernel,
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr_set = true;
     }
     AMT_HIP_CHECK(hipMemsetAsync(out_max, 0, (size_t)B * sizeof(float), st));
-    cqt_coef_kernel<<<(n_bins * 32 + 255) / 256, 256, 0, st>>>(phase_inc, length, n_bins, coef_ws);
-    AMT_LAUNCH_CHECK();
-    cqt_window_max_kernel<<<dim3(n_bins, B), 256, lds, st>>>(wave, L, wave_stride, hop, hshift, 1 + L / hop, phase_inc,
-                                                            length, coef_ws, blk_cap, (unsigned int *)out_max);
+    a.wave_stride = wave_stride; a.L = L; a.H = hop; a.T = 1 + L / hop;
+    a.out_max = (unsigned int *)out_max;
+    cqt_blocks_kernel<false><<<dim3(n_bins, B), 256, lds, st>>>(wave, phase_inc, length, coef, a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

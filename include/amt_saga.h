@@ -172,6 +172,7 @@ typedef struct amt_cqt_args {
     const uint32_t *phase_inc;  /* [n_table] per-bin frequency, cycles/sample * 2^32    */
     const int32_t *length;      /* [n_table] filter length N_k in samples               */
     const float   *ref;         /* [B] divisor (ref_C_*, training.py:340-388) or NULL    */
+    const float   *coef;        /* [n_table][192] per-bin phasor table from amt_cqt_coef() */
     float         *out;         /* [B][n_bins][frames]                                   */
     size_t         wave_stride;
     int32_t        B, L, hop, frames, n_bins, n_table;
@@ -179,15 +180,19 @@ typedef struct amt_cqt_args {
 
 int amt_cqt_slices(const amt_cqt_args *args, void *stream);
 
+/* Per-bin phasor table of a CQT grid (32 x 3 unit complex numbers per bin, f64-evaluated): computed once per
+ * (phase_inc, length) table and passed to amt_cqt_slices / amt_cqt_window_max.  coef: [n_table][192] floats. */
+int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, int n_table, float *coef, void *stream);
+
 /* Song-level CQT normalisers (training.py:271-282: ref_C_* = np.max(mid_wf.slice_C(0, duration,
  * n_frames, pitch_frames, bins_per_tone=...)), the maximum of the whole CQT): out_max[b] = max over the
  * n_bins rows of the table and over EVERY frame t = 0 .. L/hop of |C[k, t]| of window b.  O(L) per bin
  * whatever the filter length (prefix sums of per-hop block sums); hop a power of two in 128..2048;
- * AMT_E_UNSUPPORTED when L/hop block sums do not fit the LDS (windows beyond ~1300 hops).
- * coef_ws = 192 * n_bins floats of device scratch (per-bin phasor table, rebuilt by every call). */
+ * AMT_E_UNSUPPORTED when L/hop block sums do not fit the LDS (windows beyond ~1300 hops; amt_cqt_slices
+ * has the same limits). */
 int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_stride, int hop,
-                       const uint32_t *phase_inc, const int32_t *length, int n_bins,
-                       float *coef_ws, float *out_max, void *stream);
+                       const uint32_t *phase_inc, const int32_t *length, const float *coef, int n_bins,
+                       float *out_max, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * Loop glue: predicted note -> integer decisions, gather tables, guess pick,
