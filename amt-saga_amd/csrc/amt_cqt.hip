@@ -295,6 +295,50 @@ __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict
     if (lane == 0) atomicMax(a.out_max + b, __float_as_uint(vmax));   // non-negative floats order as their bits
 }
 
+// Fallback for signals whose block sums do not fit the LDS (a whole song handed to slice_C): every requested
+// frame summed directly over its own N_k samples, one workgroup per (bin, window).  Any L; 8 N_k sample visits.
+__global__ __launch_bounds__(256) void cqt_slices_direct_kernel(amt_cqt_args a) {
+    __shared__ float red[4][2];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int kt = (a.bin0 ? a.bin0[b] : 0) + k;
+    float *o = a.out + ((size_t)b * a.n_bins + k) * a.frames;
+    if (kt < 0 || kt >= a.n_table) {                // uniform
+        if (tid < a.frames) o[tid] = 0.f;
+        return;
+    }
+    const int nk = a.length[kt];
+    const unsigned int inc = a.phase_inc[kt];
+    const float *x = a.wave + (size_t)b * a.wave_stride;
+    const float inv_nk = 1.0f / (float)nk, scale = 2.0f / sqrtf((float)nk);
+    for (int j = 0; j < a.frames; ++j) {
+        const int t = a.src_frame[b * a.frames + j];
+        float re = 0.f, im = 0.f;
+        if (t >= 0) {
+            const long long s0 = (long long)t * a.hop - (nk >> 1);
+            for (int n = tid; n < nk; n += 256) {
+                const long long m = s0 + n;
+                if (m < 0 || m >= a.L) continue;
+                const float xv = x[m];
+                const float turns = (float)((unsigned int)m * inc) * 2.3283064365386963e-10f;
+                const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n * inv_nk);
+                re += xv * w * __builtin_amdgcn_cosf(turns);
+                im -= xv * w * __builtin_amdgcn_sinf(turns);
+            }
+        }
+        re = wave_sum(re); im = wave_sum(im);
+        __syncthreads();
+        if (lane == 0) { red[wid][0] = re; red[wid][1] = im; }
+        __syncthreads();
+        if (tid == 0) {
+            const float r = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+            const float i = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+            float v = t >= 0 ? sqrtf(r * r + i * i) * scale : 0.f;
+            if (a.ref) v = __fdiv_rn(v, a.ref[b]);
+            o[j] = v;
+        }
+    }
+}
+
 static int cqt_blocks_geometry(int L, int hop, int *hshift, int *blk_cap, size_t *lds) {
     if (!amt_is_pow2(hop) || hop < 128 || hop > 2048) return AMT_E_UNSUPPORTED;
     *hshift = 0;
@@ -314,7 +358,7 @@ extern "C" int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, in
 }
 
 extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
-    if (!args || !args->wave || !args->src_frame || !args->phase_inc || !args->length || !args->coef || !args->out)
+    if (!args || !args->wave || !args->src_frame || !args->phase_inc || !args->length || !args->out)
         return AMT_E_INVALID;
     const amt_cqt_args &q = *args;
     if (q.B <= 0 || q.L <= 0 || q.hop <= 0 || q.n_bins <= 0 || q.n_table <= 0) return AMT_E_INVALID;
@@ -322,8 +366,13 @@ extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
     if (q.wave_stride < (size_t)q.L) return AMT_E_SHAPE;
     CqtBlocksArgs a{};
     size_t lds;
-    const int rc = cqt_blocks_geometry(q.L, q.hop, &a.hshift, &a.blk_cap, &lds);
-    if (rc != AMT_OK) return rc;
+    if (cqt_blocks_geometry(q.L, q.hop, &a.hshift, &a.blk_cap, &lds) != AMT_OK) {
+        // hop not a power of two in 128..2048, or more hop-blocks than the LDS holds: the direct form
+        cqt_slices_direct_kernel<<<dim3(q.n_bins, q.B), 256, 0, (hipStream_t)stream>>>(q);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
+    if (!q.coef) return AMT_E_INVALID;
     static bool attr_set = false;
     if (!attr_set) {
         AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<true>,

@@ -178,6 +178,8 @@ typedef struct amt_cqt_args {
     int32_t        B, L, hop, frames, n_bins, n_table;
 } amt_cqt_args;
 
+/* Block-sum kernel (needs coef) when hop is a power of two in 128..2048 and L/hop <= ~1300 (the block sums live
+ * in LDS); otherwise every frame is summed directly over its own N_k samples (any L and hop, coef unused). */
 int amt_cqt_slices(const amt_cqt_args *args, void *stream);
 
 /* Per-bin phasor table of a CQT grid (32 x 3 unit complex numbers per bin, f64-evaluated): computed once per

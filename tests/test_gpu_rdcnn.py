@@ -327,6 +327,27 @@ def test_cqt_slices(env):
             assert np.abs(out2[i] - ref).max() <= REL * max(ref.max(), 1e-6), (fmin_midi, i)
 
 
+def test_cqt_slices_long_signal_and_odd_hop(env):
+    """amt_cqt_slices outside the block-sum kernel's range: a 20-s signal (more hop-blocks than the LDS holds) and a
+    hop that is not a power of two take the direct per-frame form; same oracle, same tolerance."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr = 44100
+    rng = np.random.default_rng(3)
+    for hop, L in ((512, 20 * sr), (441, 60000)):
+        t = np.arange(L) / sr
+        wave = np.stack([np.sin(2 * np.pi * 330 * t) * np.exp(-0.3 * t) + 0.05 * rng.standard_normal(L),
+                         0.3 * np.sin(2 * np.pi * 98 * t + 1) + 0.2 * np.sin(2 * np.pi * 1244.5 * t)]).astype(np.float32)
+        T = 1 + L // hop
+        inc, length, _ = ocqt.cqt_table(sr, 65.4, 40, 12)
+        table = audio.cqt_table(sr, 65.4, 40, 12, 'cuda')
+        src = np.array([[0, 3, T // 3, T // 2, -1, T - 9, T - 2, T - 1], [5, 6, 7, 8, 9, 10, 11, 12]], np.int32)
+        out = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src).cuda(), table, 40, hop).cpu().numpy()
+        for i in range(2):
+            ref = ocqt.cqt_frames(wave[i], src[i], inc, length, hop)
+            assert np.abs(out[i] - ref).max() <= REL * ref.max(), (hop, i)
+        assert np.all(out[0][:, 4] == 0)
+
+
 @pytest.mark.parametrize('hop,L,grids', [
     # N_k from 376 (< hop: no whole block) to 53938 (> L); L not a multiple of the hop
     (512, 512 * 40 + 123, ((27.5, 87, 12), (220.0, 60, 48), (2000.0, 24, 24))),
