@@ -278,14 +278,18 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
 
 
 def cqt_window_max(wave, table, hop):
-    """max over every bin of `table` and every STFT-grid frame 0 .. L // hop of the windows' CQT: the song-level
-    normalisers np.max(slice_C(0, duration, n_frames, ...)) of training.py:271-282.  wave [B, L] f32 device;
-    table from cqt_table(..., device).  Returns [B]."""
+    """max over every bin of `table` and every STFT-grid frame 0 .. L // hop of the signals' CQT: the song-level
+    normalisers np.max(slice_C(0, duration, n_frames, ...)) of training.py:271-282.  wave [B, L] f32 device --
+    windows, or a whole song as one row; table from cqt_table(..., device).  Returns [B]."""
     lib = _lib.load()
     B, L = wave.shape
+    n_bins = int(table[0].shape[0])
     out = empty((B,))
+    need = int(lib.amt_cqt_window_max_workspace(L, int(hop), n_bins, B))
+    ws = empty(((need + 7) // 8,), torch.float64) if need else None
     _lib.check(lib.amt_cqt_window_max(ptr(wave), B, L, _stride0(wave), int(hop), ptr(table[0]), ptr(table[1]),
-                                      ptr(table[2]), int(table[0].shape[0]), ptr(out), stream_ptr()))
+                                      ptr(table[2]), n_bins, ptr(out), ptr(ws) if need else None, need,
+                                      stream_ptr()))
     return out
 
 

@@ -150,6 +150,23 @@ class TranscriptionLoop:
         self.refs = refs
         return b
 
+    def song_levels(self, song):
+        """The song-level constants exactly as the reference computes them (training.py:269-282): ref_mag = the
+        maximum of the whole song's |STFT|, ref_C_* = the maximum of the whole song's CQT on the respective grid.
+        song: [n_samples] float32 device tensor.  Returns a dict of 0-d device tensors for the heads of this loop."""
+        if not self._dev_ready:
+            self.setup_device()
+        p = self.p
+        s = song.reshape(1, -1).to(torch.float32).contiguous()
+        out = {'ref_mag': AudioBatch(s, p.N, p.H).stft(with_phase=False).ref_max[0].clone()}
+        if 'pitch' in self.heads:
+            out['ref_C_1'] = cqt_window_max(s, self.tab_ref1, p.H)[0]
+        if 'instrument' in self.heads:
+            out['ref_C_inst'] = cqt_window_max(s, self.tab_refi, p.H)[0]
+        if 'velocity' in self.heads:
+            out['ref_C_foc'] = cqt_window_max(s, self.tab_reff, p.H)[0]
+        return out
+
     @property
     def needs_wave(self):
         return any(h in self.heads for h in ('pitch', 'instrument', 'velocity'))

@@ -61,15 +61,9 @@ def transcribe(wf, params=None, iters=5, heads=('timing', 'pitch', 'instrument',
         loop.setup_device()
     L = p.H * (p.timing_frames - 1)
     wins, starts = cut_windows(np.asarray(wf, dtype=np.float32), L, L // 2)
-    # song-level normalisers (training.py:269-282 computes ref_mag / ref_C_* once per song, as the maximum of
-    # the song's whole STFT / CQT): the maximum over every frame of every window of the song, shared by all
-    # windows.  (A window's CQT frame equals the song's wherever the filter lies inside the window; the lowest
-    # bins of the finest grid are longer than a window and see zeros where the song continues.)
-    song_refs = None
-    for b0 in range(0, len(wins), batch):
-        loop.prepare(torch.from_numpy(wins[b0:b0 + batch]).cuda())
-        part = {k: v.max() for k, v in loop.refs.items()}
-        song_refs = part if song_refs is None else {k: torch.maximum(song_refs[k], part[k]) for k in part}
+    # song-level normalisers, as training.py:269-282 computes them: once per song, the maxima of the WHOLE song's
+    # STFT and CQTs (one pass of the block-sum kernel over the song as a single signal), shared by every window
+    song_refs = loop.song_levels(torch.from_numpy(np.ascontiguousarray(wf, dtype=np.float32)).cuda())
     # the loop proper: host batches streamed through run_stream (copy of batch i+1 under the compute of batch i)
     chunks = [wins[b0:b0 + batch] for b0 in range(0, len(wins), batch)]
 

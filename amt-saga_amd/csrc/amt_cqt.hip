@@ -90,6 +90,8 @@ struct CqtBlocksArgs {
     const float *ref;           // slices mode: [B] divisor or null
     float *out;                 // slices mode: [B][n_bins][frames]
     int frames, n_bins, n_table;
+    float *fg_ws;               // GBUF: [workgroups][blk_cap][12] block sums in HBM (signals too long for the LDS)
+    double *pf_ws;              // GBUF: [workgroups][blk_cap + 1][6]
 };
 
 // SLICES = false: every frame 0 .. T-1, maximum over frames -> atomicMax(out_max[b])   (amt_cqt_window_max)
@@ -97,16 +99,20 @@ struct CqtBlocksArgs {
 //                 blocks those frames touch are summed
 // (the read-only arrays are separate __restrict__ parameters: as struct members the table reads lose the
 // no-alias guarantee and stop being scalar loads)
-template <bool SLICES>
+// GBUF = true keeps the block sums and their prefix sums in an HBM workspace instead of the LDS: a whole song as one
+// "window" (the reference's own normalisers are maxima over the song's CQT) has tens of thousands of hop-blocks.
+template <bool SLICES, bool GBUF>
 __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict__ wave,
                                                          const unsigned int *__restrict__ phase_inc,
                                                          const int *__restrict__ length,
                                                          const float *__restrict__ coef, CqtBlocksArgs a) {
     extern __shared__ double cm_smem[];
-    float *stage = (float *)cm_smem;                 // [4][CM_STAGE]; the epilogue reuses it for PF
-    double *pf = cm_smem;                            // [nblk + 1][6]
-    float *fg = stage + max(4 * CM_STAGE, (a.blk_cap + 1) * 12);        // [blk_cap][12]  (F_j, G_j)
+    float *stage = (float *)cm_smem;                 // [4][CM_STAGE]; the LDS form's epilogue reuses it for PF
     const int k = blockIdx.x, b = blockIdx.y;
+    const size_t wg = (size_t)b * gridDim.x + k;
+    double *pf = GBUF ? a.pf_ws + wg * ((size_t)a.blk_cap + 1) * 6 : cm_smem;                        // [nblk + 1][6]
+    float *fg = GBUF ? a.fg_ws + wg * (size_t)a.blk_cap * 12
+                     : stage + max(4 * CM_STAGE, (a.blk_cap + 1) * 12);                               // [blk_cap][12]  (F_j, G_j)
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int L = a.L, H = a.H, hshift = a.hshift, T = a.T;
     int kt = k, t_min = 0, t_max = T - 1;
@@ -375,40 +381,59 @@ extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
     if (!q.coef) return AMT_E_INVALID;
     static bool attr_set = false;
     if (!attr_set) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<true>,
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<true, false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr_set = true;
     }
     a.wave_stride = q.wave_stride; a.L = q.L; a.H = q.hop; a.T = 1 + q.L / q.hop;
     a.src_frame = q.src_frame; a.bin0 = q.bin0; a.ref = q.ref; a.out = q.out;
     a.frames = q.frames; a.n_bins = q.n_bins; a.n_table = q.n_table;
-    cqt_blocks_kernel<true><<<dim3(q.n_bins, q.B), 256, lds, (hipStream_t)stream>>>(q.wave, q.phase_inc, q.length,
+    cqt_blocks_kernel<true, false><<<dim3(q.n_bins, q.B), 256, lds, (hipStream_t)stream>>>(q.wave, q.phase_inc, q.length,
                                                                                      q.coef, a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
+// bytes of HBM workspace amt_cqt_window_max needs for (L, hop, n_bins, B): 0 while the block sums fit the LDS
+extern "C" size_t amt_cqt_window_max_workspace(int L, int hop, int n_bins, int B) {
+    int hshift, blk_cap;
+    size_t lds;
+    if (L <= 0 || hop <= 0 || n_bins <= 0 || B <= 0) return 0;
+    if (cqt_blocks_geometry(L, hop, &hshift, &blk_cap, &lds) == AMT_OK) return 0;
+    return (size_t)n_bins * B * ((size_t)blk_cap * 12 * sizeof(float) + ((size_t)blk_cap + 1) * 6 * sizeof(double));
+}
+
 extern "C" int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_stride, int hop,
                                   const uint32_t *phase_inc, const int32_t *length, const float *coef, int n_bins,
-                                  float *out_max, void *stream) {
+                                  float *out_max, void *workspace, size_t workspace_bytes, void *stream) {
     if (!wave || !phase_inc || !length || !coef || !out_max) return AMT_E_INVALID;
     if (B <= 0 || L <= 0 || n_bins <= 0) return AMT_E_INVALID;
     if (wave_stride < (size_t)L) return AMT_E_SHAPE;
+    if (!amt_is_pow2(hop) || hop < 128 || hop > 2048) return AMT_E_UNSUPPORTED;
     CqtBlocksArgs a{};
     size_t lds;
-    const int rc = cqt_blocks_geometry(L, hop, &a.hshift, &a.blk_cap, &lds);
-    if (rc != AMT_OK) return rc;
+    const bool in_lds = cqt_blocks_geometry(L, hop, &a.hshift, &a.blk_cap, &lds) == AMT_OK;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr_set = true;
-    }
     AMT_HIP_CHECK(hipMemsetAsync(out_max, 0, (size_t)B * sizeof(float), st));
     a.wave_stride = wave_stride; a.L = L; a.H = hop; a.T = 1 + L / hop;
     a.out_max = (unsigned int *)out_max;
-    cqt_blocks_kernel<false><<<dim3(n_bins, B), 256, lds, st>>>(wave, phase_inc, length, coef, a);
+    if (in_lds) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_blocks_kernel<false, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            attr_set = true;
+        }
+        cqt_blocks_kernel<false, false><<<dim3(n_bins, B), 256, lds, st>>>(wave, phase_inc, length, coef, a);
+    } else {
+        // a signal of more hop-blocks than the LDS holds (a whole song): block sums in the caller's HBM workspace
+        const size_t need = amt_cqt_window_max_workspace(L, hop, n_bins, B);
+        if (!workspace || workspace_bytes < need) return AMT_E_NOMEM;
+        a.pf_ws = (double *)workspace;               // doubles first: 8-byte aligned whatever blk_cap is
+        a.fg_ws = (float *)(a.pf_ws + (size_t)n_bins * B * ((size_t)a.blk_cap + 1) * 6);
+        cqt_blocks_kernel<false, true><<<dim3(n_bins, B), 256, 4 * CM_STAGE * sizeof(float), st>>>(wave, phase_inc, length,
+                                                                                                   coef, a);
+    }
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

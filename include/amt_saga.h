@@ -188,13 +188,14 @@ int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, int n_table, 
 
 /* Song-level CQT normalisers (training.py:271-282: ref_C_* = np.max(mid_wf.slice_C(0, duration,
  * n_frames, pitch_frames, bins_per_tone=...)), the maximum of the whole CQT): out_max[b] = max over the
- * n_bins rows of the table and over EVERY frame t = 0 .. L/hop of |C[k, t]| of window b.  O(L) per bin
- * whatever the filter length (prefix sums of per-hop block sums); hop a power of two in 128..2048;
- * AMT_E_UNSUPPORTED when L/hop block sums do not fit the LDS (windows beyond ~1300 hops; amt_cqt_slices
- * has the same limits). */
+ * n_bins rows of the table and over EVERY frame t = 0 .. L/hop of |C[k, t]| of signal b -- a window, or a whole
+ * song.  O(L) per bin whatever the filter length (prefix sums of per-hop block sums); hop a power of two in
+ * 128..2048.  Up to ~1300 hops the block sums live in LDS; longer signals need
+ * amt_cqt_window_max_workspace(L, hop, n_bins, B) bytes of device scratch (AMT_E_NOMEM if it is missing). */
+size_t amt_cqt_window_max_workspace(int L, int hop, int n_bins, int B);
 int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_stride, int hop,
                        const uint32_t *phase_inc, const int32_t *length, const float *coef, int n_bins,
-                       float *out_max, void *stream);
+                       float *out_max, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * Loop glue: predicted note -> integer decisions, gather tables, guess pick,

@@ -25,3 +25,15 @@ for name, bpt in (('ref_C_1', 1), ('ref_C_inst', p.instrument_bins_per_tone), ('
     sb = B * span * bpt * L
     print('%-10s %5d bins  %7.1f ms / %d windows   %.2f T sample-bins/s   max %.4f' %
           (name, span * bpt, ms, B, sb / ms / 1e9, float(out.max())), flush=True)
+
+# a whole song as one signal (transcribe.py / TranscriptionLoop.song_levels): 3 minutes
+Ls = 180 * p.sr
+song = (torch.rand(1, Ls, device='cuda') - 0.5) * 0.2
+for name, bpt in (('ref_C_1', 1), ('ref_C_inst', p.instrument_bins_per_tone), ('ref_C_foc', 4 * p.instrument_bins_per_tone)):
+    tab = cqt_table(p.sr, f_lo, span * bpt, 12 * bpt, 'cuda')
+    cqt_window_max(song, tab, p.H)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = cqt_window_max(song, tab, p.H)
+    torch.cuda.synchronize()
+    print('song 180 s  %-10s %5d bins  %7.1f ms   max %.4f' % (name, span * bpt, (time.perf_counter() - t0) * 1e3, float(out[0])), flush=True)

@@ -380,6 +380,29 @@ def test_cqt_window_max(env, hop, L, grids):
         assert got[2] == 0.0
 
 
+def test_cqt_window_max_whole_song(env):
+    """A whole song as ONE signal (the reference's normalisers are maxima over the song's CQT, training.py:271-282):
+    1700 hop-blocks do not fit the LDS, the block sums go through the HBM workspace.  Same oracle."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr, hop = 44100, 512
+    L = 1700 * hop + 77
+    lib = env['audio']._lib.load()
+    assert lib.amt_cqt_window_max_workspace(L, hop, 30, 2) > 0 and lib.amt_cqt_window_max_workspace(263680, hop, 30, 2) == 0
+    rng = np.random.default_rng(8)
+    t = np.arange(L) / sr
+    env_ = np.exp(-((t - 11.0) / 2.5) ** 2)
+    wave = np.stack([np.sin(2 * np.pi * 220 * t) * env_ + 0.02 * rng.standard_normal(L),
+                     0.3 * np.sin(2 * np.pi * 55 * t) * (t > 15) + 0.1 * np.sin(2 * np.pi * 3520 * t) * (t < 2)]).astype(np.float32)
+    wd = torch.from_numpy(wave).cuda()
+    for fmin, n_bins, bpo in ((27.5, 30, 4), (27.5, 6, 192)):
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        got = audio.cqt_window_max(wd, table, hop).cpu().numpy()
+        for i in range(2):
+            ref = ocqt.cqt_window_max(wave[i], inc, length, hop)
+            assert abs(got[i] - ref) <= REL * ref, (fmin, i, got[i], ref)
+
+
 def test_cqt_window_max_full_window(env):
     """One 6 s window (516 frames) on the pitch head's normaliser grid: kernel vs oracle, and the maximum really is
     attained away from the 8 sampled frames the round-1 shortcut looked at."""

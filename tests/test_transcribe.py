@@ -45,6 +45,15 @@ def test_transcribe_flac_to_midi(tmp_path):
     # copy overlapped): the events do not depend on how the windows are batched
     notes_b, evs_b = tr.transcribe(back, p, iters=2, heads=('timing', 'pitch', 'instrument', 'velocity'), batch=3)
     assert np.array_equal(evs_b, evs) and notes_b == notes
+    # song-level constants: the product's whole-song maxima vs the oracle's (training.py:269-282)
+    from amt_saga.loop import TranscriptionLoop
+    from oracle import audio as oa, cqt as ocqt
+    lv = TranscriptionLoop(p, heads=('timing', 'pitch'), iters=1).song_levels(torch.from_numpy(back).cuda())
+    ref_mag = oa.magphase(oa.stft(back, p.N, p.H))[0].max()
+    tab = ocqt.cqt_table(p.sr, float(oa.midi_to_hz(p.pitch_low)), p.pitch_high - p.pitch_low, 12)
+    ref_c1 = ocqt.cqt_window_max(back, tab[0], tab[1], p.H)
+    assert abs(float(lv['ref_mag']) - ref_mag) <= 1e-4 * ref_mag
+    assert abs(float(lv['ref_C_1']) - ref_c1) <= 1e-4 * ref_c1
     mid = str(tmp_path / 'out.mid')
     events.write_midi(notes, mid)
     rd = events.read_midi(mid)
