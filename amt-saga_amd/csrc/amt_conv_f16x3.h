@@ -114,9 +114,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 // MASKED = true is the small-image form: whole H x W <= 64 images of several windows per workgroup,
 // no halo in LDS; every tap's A-fragment address is chosen per lane (in-bounds neighbour or one
 // all-zero position), so the "same" padding costs no LDS.
-template <int KH, int KW, int CIN, bool MASKED>
-__global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const uint4 *__restrict__ w16s,
-                                                             HxScale hs) {
+// MS = 16-position M-subtiles per wave: 2 (eight waves, 512 threads, four waves per SIMD) or 4 (four waves of 64
+// positions, 256 threads, two waves per SIMD with twice the registers: a B fragment then feeds four M-subtiles
+// instead of two -- 12 ds_read_b128 per 24 MFMAs instead of 8 per 12).
+template <int KH, int KW, int CIN, bool MASKED, int MS = 2>
+__global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel(ConvParams p, const uint4 *__restrict__ w16s,
+                                                                                  HxScale hs) {
+    constexpr int NT = 1024 / MS;                                   // threads per workgroup (256 positions / (16 MS) waves)
+    constexpr int NIT = MS == 2 ? HXS_NIT : 4;                      // prefetched staging items per thread
     constexpr int NCHUNK = CIN / BX_CC;
     constexpr int NTAPS = KH * KW;
     constexpr int PCAP = 256;
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     constexpr int GT = 2 * GROUP;                                   // taps per group
     constexpr int NG = NSLAB / GROUP, NGT = NCHUNK * NG;
     constexpr int GV4 = GROUP * SLAB_V4;
-    constexpr int WPT = GV4 / 512;
-    static_assert(NSLAB % GROUP == 0 && GV4 % 512 == 0, "whole groups");
+    constexpr int WPT = GV4 / NT;
+    static_assert(NSLAB % GROUP == 0 && GV4 % NT == 0, "whole groups");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4 *wbuf = reinterpret_cast<uint4 *>(smem);                  // [2][GV4]
     int *pos_sp = reinterpret_cast<int *>(wbuf + 2 * GV4);          // [PCAP]
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     // its latency runs with the weight / tile loads issued below; the tables are written after those
     float my_amax = 0.f;
     if (tid < p.NWIN && win0 + tid < p.B) my_amax = hs.amax_in[win0 + tid];
-    for (int q = tid; q < PCAP; q += 512) {
+    for (int q = tid; q < PCAP; q += NT) {
         const int w_ = q / ptile, rem = q - w_ * ptile;
         const int r = rem / p.TW, c = rem - r * p.TW;
         const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
@@ -172,23 +177,23 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     // is the next column (+one position pitch).  With this order the lanes a ds_read_b128 services
     // together (0-3,12-15,20-27 ...) read 16 distinct slots or the same address: conflict-free.  Two 16-position M-subtiles x two 16-channel
     // N-subtiles x (hi, lo) = eight 4-register accumulators.
-    int abase[2];
-    unsigned lrc = 0;                                      // MASKED: (row, col) of both M-subtiles, 8 bits each
+    int abase[MS];
+    unsigned lrc[MS];                                      // MASKED: (row, col) of the M-subtiles, 8 bits each
     const int tsel = (lane >> 4) & 1;                      // this lane's tap of a tap pair
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        int q = wid * 32 + ms * 16 + (lane & 15);
+    for (int ms = 0; ms < MS; ++ms) {
+        int q = wid * (16 * MS) + ms * 16 + (lane & 15);
         int w_ = q / ptile, rem = q - w_ * ptile;
         int r = rem / p.TW, c = rem - r * p.TW;
         if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
         abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16 + (MASKED ? 0 : tsel * HX_PSTRIDE);
-        lrc |= ((unsigned)r | ((unsigned)c << 8)) << (16 * ms);
+        lrc[ms] = (unsigned)r | ((unsigned)c << 8);
     }
     const int zero_off = p.NWIN * THin * RP * HX_PSTRIDE + (lane >> 5) * 16;
     if (MASKED && tid < 20) reinterpret_cast<unsigned *>(in_lds + p.NWIN * THin * RP * HX_PSTRIDE)[tid] = 0u;
-    f32x4 hi[2][2], lo[2][2];
+    f32x4 hi[MS][2], lo[MS][2];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
@@ -199,17 +204,17 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         const uint4 *src = w16 + (size_t)gg * GV4 + tid;
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * 512) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wp[i]) : "v"(src + i * NT) : "memory");
     };
     // staged 32-byte items of this thread (the same for every chunk): up to HXS_NIT of them are
     // prefetched; the third slot exists only in the waves that have one (tiles of 1025..1536 items)
     const int items = p.NWIN * THin * TWin * 2;
-    int sdst[HXS_NIT];                                     // LDS offset, -1: no item
-    const float *ssrc[HXS_NIT];                            // chunk-0 source, null: outside the image (zeros)
-    const bool third = 2 * 512 + wid * 64 < items;         // wave-uniform
+    int sdst[NIT];                                         // LDS offset, -1: no item
+    const float *ssrc[NIT];                                // chunk-0 source, null: outside the image (zeros)
+    auto slot_live = [&](int u) { return u < 2 || u * NT + wid * 64 < items; };     // wave-uniform: slots past the tile
 #pragma unroll
-    for (int u = 0; u < HXS_NIT; ++u) {
-        const int it = u * 512 + tid;
+    for (int u = 0; u < NIT; ++u) {
+        const int it = u * NT + tid;
         sdst[u] = -1; ssrc[u] = nullptr;
         if (it < items) {
             const int cg = it & 1, pc = it >> 1;
@@ -221,11 +226,11 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 ssrc[u] = p.in + (size_t)gw * p.in_win_stride + ((size_t)gr * p.W + gc) * CIN + cg * 8;
         }
     }
-    u32x4 sv[HXS_NIT][2];                                  // staged values in flight (inline-asm loads)
+    u32x4 sv[NIT][2];                                      // staged values in flight (inline-asm loads)
     auto stage_issue = [&](int ch) {
 #pragma unroll
-        for (int u = 0; u < HXS_NIT; ++u) {
-            if (u == 2 && !third) continue;
+        for (int u = 0; u < NIT; ++u) {
+            if (!slot_live(u)) continue;
             const float *src = ssrc[u] ? ssrc[u] + ch * BX_CC : p.in;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sv[u][0]) : "v"(src) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sv[u][1]) : "v"(src) : "memory");
@@ -262,17 +267,17 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         if constexpr (!MASKED) {
         if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < HXS_NIT; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
+        for (int u = 0; u < NIT; ++u) asm volatile("" : "+v"(sv[u][0]), "+v"(sv[u][1]));   // tie the values to the wait
 #pragma unroll
-        for (int u = 0; u < HXS_NIT; ++u) {
-            if (sdst[u] < 0 || (u == 2 && !third)) continue;
+        for (int u = 0; u < NIT; ++u) {
+            if (sdst[u] < 0 || !slot_live(u)) continue;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = ssrc[u] ? __uint_as_float(sv[u][e >> 2][e & 3]) : 0.f;
             split_store(v, sdst[u] & 0xFFFFFF, win_is[sdst[u] >> 24]);
         }
         }
-        for (int it = (MASKED ? 0 : HXS_NIT * 512) + tid; it < items; it += 512) { // masked tiles; items beyond the prefetch slots
+        for (int it = (MASKED ? 0 : NIT * NT) + tid; it < items; it += NT) { // masked tiles; items beyond the prefetch slots
             const int cg = it & 1, pc = it >> 1;
             const int wr = pc / TWin, ci = pc - wr * TWin;
             const int w_ = wr / THin, ri = wr - w_ * THin;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         if (ch == 0) {                                    // weight group 0 -> LDS, group 1 -> prefetch registers
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * 512] = wp[i];
+            for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4 *>(wbuf)[tid + i * NT] = wp[i];
             if (NGT > 1) issue(1);
         }
         __syncthreads();                                   // tile staged, weight group parked
@@ -305,8 +310,8 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 const int dy = tap / KW, dx = tap - dy * KW;
                 const char *ap;
                 if constexpr (MASKED) {
-                    const int rr = (int)((lrc >> (16 * ms)) & 255u) + dy - PAD_T;
-                    const int cc = (int)((lrc >> (16 * ms + 8)) & 255u) + dx + tsel - PAD_L;
+                    const int rr = (int)(lrc[ms] & 255u) + dy - PAD_T;
+                    const int cc = (int)((lrc[ms] >> 8) & 255u) + dx + tsel - PAD_L;
                     const bool inb = (unsigned)rr < (unsigned)p.H && (unsigned)cc < (unsigned)p.W;
                     ap = in_lds + (inb ? abase[ms] + ((dy - PAD_T) * RP + (dx + tsel - PAD_L)) * HX_PSTRIDE : zero_off);
                 } else {
@@ -331,17 +336,18 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                 for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) b[ns][pl].u = wb[((tp * 2 + pl) * 2 + ns) * 64];
-                loadA(tp, 0);
-                mfma6(0);
-                loadA(tp, 1);
-                mfma6(1);
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    loadA(tp, ms);
+                    mfma6(ms);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (gg + 1 < NGT) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // group gg+1 has landed in registers
                 u32x4 *dst = reinterpret_cast<u32x4 *>(wbuf + ((gg + 1) & 1) * GV4);
 #pragma unroll
-                for (int i = 0; i < WPT; ++i) dst[tid + i * 512] = wp[i];
+                for (int i = 0; i < WPT; ++i) dst[tid + i * NT] = wp[i];
                 if (gg + 2 < NGT) issue(gg + 2);
             }
             if (g + 1 < NG) __syncthreads();
@@ -354,23 +360,23 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         pos_os[tid] = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
     }
     __syncthreads();
-    float *tb = reinterpret_cast<float *>(in_lds) + wid * (32 * HX_TPITCH);
+    float *tb = reinterpret_cast<float *>(in_lds) + wid * (16 * MS * HX_TPITCH);
     const int c4 = (lane & 7) * 4;
     float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + cout_off + c4);
     if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + cout_off + c4);
     // D of a 16x16 MFMA: lane l holds rows 4*(l/16) + e, column l%16
-    float osc[2][4];                                   // 2^-(sa + sw) of this lane's eight rows
+    float osc[MS][4];                                  // 2^-(sa + sw) of this lane's rows
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) osc[ms][e] = pos_os[wid * 32 + ms * 16 + 4 * (lane >> 4) + e];
+        for (int e = 0; e < 4; ++e) osc[ms][e] = pos_os[wid * (16 * MS) + ms * 16 + 4 * (lane >> 4) + e];
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
         const int jn = cout_off + ns * 16 + (lane & 15);
         const float s1 = p.s1[jn], t1 = p.t1[jn];
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = ms * 16 + 4 * (lane >> 4) + e;
@@ -378,18 +384,19 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
                     sigmoidf_(((hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * osc[ms][e]) * s1 + t1);
             }
     }
-    int spq[4], gwq[4];
-    float4 scv[4];
+    constexpr int NR = 2 * MS;                             // eight rows of the wave's patch per pass
+    int spq[NR], gwq[NR];
+    float4 scv[NR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wid * 32 + (lane >> 3) + 8 * i;
+    for (int i = 0; i < NR; ++i) {
+        const int q = wid * (16 * MS) + (lane >> 3) + 8 * i;
         spq[i] = pos_sp[q];
         gwq[i] = pos_win[q];
     }
     const bool has_sc = p.sc || p.sc1;
     if (p.sc) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const float *scp = p.sc + (size_t)gwq[i] * p.sc_win_stride + (size_t)max(spq[i], 0) * p.cout_total + cout_off + c4;
             scv[i] = spq[i] >= 0 ? *reinterpret_cast<const float4 *>(scp) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -399,15 +406,15 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
         const float4 s4 = *reinterpret_cast<const float4 *>(p.sc1_s + cout_off + c4);
         const float4 t4 = *reinterpret_cast<const float4 *>(p.sc1_t + cout_off + c4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const float x = spq[i] >= 0 ? p.sc1[(size_t)gwq[i] * p.sc1_win_stride + spq[i]] : 0.f;
             scv[i] = make_float4(fmaf(x, w4.x, 0.f) * s4.x + t4.x, fmaf(x, w4.y, 0.f) * s4.y + t4.y,
                                  fmaf(x, w4.z, 0.f) * s4.z + t4.z, fmaf(x, w4.w, 0.f) * s4.w + t4.w);
         }
     }
-    float rmax[4];
+    float rmax[NR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * i) * HX_TPITCH + c4);
         rmax[i] = 0.f;
         if (spq[i] < 0) continue;
@@ -423,12 +430,14 @@ __global__ __launch_bounds__(512, 4) void conv_f16x3s_kernel(ConvParams p, const
     // max |output| per window for the next layer's operand scaling
     if (hs.amax_out) {
         if (p.NWIN == 1) {
-            float m = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) m = fmaxf(m, rmax[i]);
             m = wave_max(m);
             if (lane == 0) atomicMax(win_max, __float_as_int(m));
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 float m = rmax[i];                      // eight lanes share a row
                 m = fmaxf(m, __shfl_xor(m, 1, 64));
                 m = fmaxf(m, __shfl_xor(m, 2, 64));

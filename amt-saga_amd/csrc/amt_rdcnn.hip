@@ -1114,9 +1114,20 @@ static void choose_tile_h(ConvOp &c) {
     }
 }
 
-template <int KH, int KW, int CIN, bool MASKED>
+// AMT_CONV_MS=4 (diagnostic, 4 x 16 kernels only): four M-subtiles per wave -- 64 positions, 256 threads, 12 LDS
+// fragment reads per 24 MFMAs instead of 8 per 12.  Parity-green and 3 % SLOWER than the default (385 vs 397 TFLOP/s
+// on the 20 x 516 layers): the kernel is not bound by LDS reads, and two waves per SIMD hide less.
+static int conv_ms_choice() {
+    static int ms = -1;
+    if (ms < 0) {
+        const char *e = getenv("AMT_CONV_MS");
+        ms = (e && atoi(e) == 4) ? 4 : 2;
+    }
+    return ms;
+}
+template <int KH, int KW, int CIN, bool MASKED, int MS = 2>
 static int launch_convs_t(const ConvOp &c, ConvParams p, const float *amax_in, float *amax_out, hipStream_t st) {
-    auto kern = conv_f16x3s_kernel<KH, KW, CIN, MASKED>;
+    auto kern = conv_f16x3s_kernel<KH, KW, CIN, MASKED, MS>;
     static bool attr_set = false;
     if (!attr_set) {
         AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1128,7 +1139,7 @@ static int launch_convs_t(const ConvOp &c, ConvParams p, const float *amax_in, f
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
     HxScale hs{amax_in, amax_out, c.sw};
-    kern<<<dim3(grid, c.nsliceh), 512, c.ldsh, st>>>(p, c.whs, hs);
+    kern<<<dim3(grid, c.nsliceh), 1024 / MS, c.ldsh, st>>>(p, c.whs, hs);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
@@ -1137,8 +1148,12 @@ static int launch_convh_k(const ConvOp &c, const ConvParams &p, const float *ama
     // every layer runs 32-wide N-slices (blockIdx.y) of the single-tile kernel; small images its masked form
     if (!c.whs || c.cwh != 32) return AMT_E_UNSUPPORTED;
 #define HXS_CASE(CI)                                                                       \
-    if (c.cin == CI) return c.maskedh ? launch_convs_t<KH, KW, CI, true>(c, p, amax_in, amax_out, st)   \
-                                      : launch_convs_t<KH, KW, CI, false>(c, p, amax_in, amax_out, st);
+    if (c.cin == CI) {                                                                     \
+        if (c.maskedh) return launch_convs_t<KH, KW, CI, true>(c, p, amax_in, amax_out, st);              \
+        if constexpr (KW == 16)                                                            \
+            if (conv_ms_choice() == 4) return launch_convs_t<KH, KW, CI, false, 4>(c, p, amax_in, amax_out, st); \
+        return launch_convs_t<KH, KW, CI, false>(c, p, amax_in, amax_out, st);            \
+    }
     HXS_CASE(32) HXS_CASE(64) HXS_CASE(128)
 #undef HXS_CASE
     return AMT_E_UNSUPPORTED;
