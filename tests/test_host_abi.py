@@ -135,5 +135,8 @@ def test_split_bf16_kernels_are_spill_free():
         scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1))
         vgpr = int(re.search(r'\bVGPRs: (\d+)', b).group(1))
         assert spill == 0 and scratch == 0, (name, spill, scratch)
-        assert vgpr <= 128, (name, vgpr)          # 4 waves per SIMD = two workgroups per CU
+        # 4 waves per SIMD = two 512-thread workgroups per CU; the diagnostic four-subtile form (template
+        # argument MS = 4, 256-thread workgroups) runs two waves per SIMD by design
+        ms4 = 'conv_f16x3s_kernel' in name and 'ELi4EEv' in name
+        assert vgpr <= (256 if ms4 else 128), (name, vgpr)
     assert seen >= 24 + 18
