@@ -355,6 +355,8 @@ def test_cqt_slices_long_signal_and_odd_hop(env):
     (512, 512 * 52, ((27.5, 40, 192),)),
     (1024, 1024 * 21 + 7, ((55.0, 75, 12), (27.5, 24, 192))),
     (256, 256 * 64 + 200, ((110.0, 48, 24),)),
+    # a signal shorter than one staging run (2048 samples) and than most filters
+    (128, 300, ((2000.0, 12, 12), (440.0, 6, 24))),
 ])
 def test_cqt_window_max(env, hop, L, grids):
     """Song-level normalisers (training.py:271-282): max over every bin and EVERY frame of the window's CQT,
