@@ -28,6 +28,8 @@ prepare(), as the reference computes them once per song (training.py:269-282).
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -51,6 +53,7 @@ class TranscriptionLoop:
         if guess not in ('bank', 'render'):
             raise ValueError('Requested attribute does not exist')
         self.guess = guess
+        self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
         self.lib = _lib.load()
         # default seeds: synthetic timing_start / timing_end nets whose (nearly input-independent)
         # outputs satisfy onset < end, so the short-window features are not empty
@@ -182,8 +185,22 @@ class TranscriptionLoop:
         onset = end = pitch = program = velocity = None
         if 'timing' in self.heads:
             ct = b.compress_bands(p.timing_bands, self.refs['ref_mag'], p.timing_frames)
-            ts = self.nets['timing_start'].classify(ct)
-            te = self.nets['timing_end'].classify(ct)
+            if self.timing_streams == 2:
+                # the two timing networks read the same features and are independent: timing_end on a second stream
+                # fills the tails of timing_start's small-image launches (5 x 8 and 10 x 64 layers)
+                cur = torch.cuda.current_stream()
+                if getattr(self, '_side_stream', None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side = self._side_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    te = self.nets['timing_end'].classify(ct)
+                ts = self.nets['timing_start'].classify(ct)
+                cur.wait_stream(side)
+                te.record_stream(cur)
+            else:
+                ts = self.nets['timing_start'].classify(ct)
+                te = self.nets['timing_end'].classify(ct)
             onset = self._round(ts, 0, T - 1)
             end = self._round(te, 0, T)
         else:

@@ -197,3 +197,19 @@ def test_run_stream_overlapped_copy_equals_run(env):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert list(lp.run_stream([])) == []
+
+
+def test_timing_heads_on_two_streams(env):
+    """AMT_TIMING_STREAMS=2 / TranscriptionLoop.timing_streams = 2: timing_end on a second stream, joined before the
+    rounding.  Same events, bit for bit."""
+    torch, synth = env['torch'], env['synth']
+    p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
+    lp = env['loop'].TranscriptionLoop(p, heads=('timing', 'pitch', 'velocity'), iters=2).setup_device()
+    L = p.H * (p.timing_frames - 1)
+    wave = synth.make_windows(12, L, seed=77, notes_per_window=(1, 3), device='cuda')[0]
+    lp.timing_streams = 1
+    a = lp.run(wave)[0].cpu().numpy()
+    lp.timing_streams = 2
+    b = lp.run(wave)[0].cpu().numpy()
+    c = lp.run(wave)[0].cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a, c)
