@@ -73,6 +73,7 @@ struct HxScale {
     const float *amax_in;     // device [B]: max |input| of every window of this launch
     float *amax_out;          // device [B] or null: max |output| per window (atomicMax, zeroed by the caller)
     int sw;                   // weights were scaled by 2^sw on the host
+    unsigned long long *ts;   // diagnostic (AMT_CONV_TS): four 100-MHz timestamps per workgroup, or null
 };
 #define HX_MAXWIN 64                         // windows per workgroup tile (masked tiles of >= 4 positions)
 
@@ -84,6 +85,11 @@ __device__ __forceinline__ int hx_scale_exp(float amax) {
     else return 0;
     return min(max(13 - e, -90), 90);
 }
+
+// floor(q / d) for 0 <= q < 2^20 with rd = 1.0f / d: (q + 0.5) rd is off by < 2^-3 / d from (q + 0.5) / d, which
+// lies at least 0.5 / d from the next integer.  Two instructions instead of the ~40 of an integer division: the
+// tile tables sit in front of the first load of a workgroup.
+__device__ __forceinline__ int hx_div(int q, float rd) { return (int)(((float)q + 0.5f) * rd); }
 
 // max |x| per window: grid (blocks, B); out[b] must be zero before
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, size_t stride,
@@ -142,10 +148,13 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     float *pos_os = reinterpret_cast<float *>(pos_win + PCAP);      // [PCAP] 2^-(sa + sw) of the row's window
     float *win_is = pos_os + PCAP;                                  // [HX_MAXWIN] 2^sa of the tile's windows
     int *win_max = reinterpret_cast<int *>(win_is + HX_MAXWIN);     // [HX_MAXWIN] max |output| (float bits)
-    char *in_lds = reinterpret_cast<char *>(win_max + HX_MAXWIN);   // [POSIN][80 B]
+    float *bnp = reinterpret_cast<float *>(win_max + HX_MAXWIN);    // [4][32] s1, t1, s2, t2 of this 32-channel slice
+    char *in_lds = reinterpret_cast<char *>(bnp + 128);             // [POSIN][80 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long *tsp = hs.ts ? hs.ts + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
+    if (tsp && tid == 0) tsp[0] = wall_clock64();
     const int THin = MASKED ? p.TH : p.TH + KH - 1, TWin = MASKED ? p.TW : p.TW + KW - 1;
     const int RP = MASKED ? p.TW : bx_row_pitch(p.TW, TWin);
     const int cout_off = blockIdx.y * 32;
@@ -160,17 +169,17 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     const int win0 = bid * p.NWIN;
     const int r0 = tr * p.TH, c0 = tc * p.TW;
     const int ptile = p.TH * p.TW;
+    const float rd_ptile = 1.0f / (float)ptile, rd_tw = 1.0f / (float)p.TW;
+    const float rd_twin = 1.0f / (float)TWin, rd_thin = 1.0f / (float)THin;
 
-    // per-window scales of this tile: the measured max |input| of each window is requested first, so that
-    // its latency runs with the weight / tile loads issued below; the tables are written after those
+    // per-window scales of this tile and the folded BN parameters of this channel slice: requested first, so that
+    // their latency runs with the weight / tile loads issued below; the tables are written after those
     float my_amax = 0.f;
     if (tid < p.NWIN && win0 + tid < p.B) my_amax = hs.amax_in[win0 + tid];
-    for (int q = tid; q < PCAP; q += NT) {
-        const int w_ = q / ptile, rem = q - w_ * ptile;
-        const int r = rem / p.TW, c = rem - r * p.TW;
-        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
-        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
-        pos_win[q] = win0 + w_;
+    float my_bn = 0.f;
+    if (tid < 128) {
+        const float *src = tid < 32 ? p.s1 : tid < 64 ? p.t1 : tid < 96 ? p.s2 : p.t2;
+        my_bn = src ? src[cout_off + (tid & 31)] : (tid < 96 ? 1.f : 0.f);      // no residual BN: s2 = 1, t2 = 0
     }
     // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
     // PAIR of taps x 16 channels: k-group g = (tap t + g%2, channels 8*(g/2) .. +7); the second tap
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         int q = wid * (16 * MS) + ms * 16 + (lane & 15);
-        int w_ = q / ptile, rem = q - w_ * ptile;
-        int r = rem / p.TW, c = rem - r * p.TW;
+        int w_ = hx_div(q, rd_ptile), rem = q - w_ * ptile;
+        int r = hx_div(rem, rd_tw), c = rem - r * p.TW;
         if (w_ >= p.NWIN) { w_ = 0; r = 0; c = 0; }
         abase[ms] = ((w_ * THin + r) * RP + c) * HX_PSTRIDE + (lane >> 5) * 16 + (MASKED ? 0 : tsel * HX_PSTRIDE);
         lrc[ms] = (unsigned)r | ((unsigned)c << 8);
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
         sdst[u] = -1; ssrc[u] = nullptr;
         if (it < items) {
             const int cg = it & 1, pc = it >> 1;
-            const int wr = pc / TWin, ci = pc - wr * TWin;
-            const int w_ = wr / THin, ri = wr - w_ * THin;
+            const int wr = hx_div(pc, rd_twin), ci = pc - wr * TWin;
+            const int w_ = hx_div(wr, rd_thin), ri = wr - w_ * THin;
             const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
             sdst[u] = ((wr * RP + ci) * HX_PSTRIDE + cg * 16) | (w_ << 24);       // LDS offset | window slot
             if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W)
@@ -253,10 +262,19 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     };
     issue(0);                                             // first weight group: lands while the first tile is staged
     if constexpr (!MASKED) stage_issue(0);                 // (masked tiles are small: staged synchronously, registers saved)
+    // everything below runs under the latency of the loads just issued
+    for (int q = tid; q < PCAP; q += NT) {
+        const int w_ = hx_div(q, rd_ptile), rem = q - w_ * ptile;
+        const int r = hx_div(rem, rd_tw), c = rem - r * p.TW;
+        const bool ok = w_ < p.NWIN && (win0 + w_) < p.B && (r0 + r) < p.H && (c0 + c) < p.W;
+        pos_sp[q] = ok ? (r0 + r) * p.W + (c0 + c) : -1;
+        pos_win[q] = win0 + w_;
+    }
     if (tid < HX_MAXWIN) {
         win_is[tid] = __uint_as_float((unsigned)(127 + hx_scale_exp(my_amax)) << 23);     // 2^sa
         win_max[tid] = 0;
     }
+    if (tid < 128) bnp[tid] = my_bn;
     for (int ch = 0; ch < NCHUNK; ++ch) {
         __syncthreads();
         // ---- stage + split the input tile (16 channels).  The first pass (two items per thread) was
@@ -279,8 +297,8 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
         }
         for (int it = (MASKED ? 0 : NIT * NT) + tid; it < items; it += NT) { // masked tiles; items beyond the prefetch slots
             const int cg = it & 1, pc = it >> 1;
-            const int wr = pc / TWin, ci = pc - wr * TWin;
-            const int w_ = wr / THin, ri = wr - w_ * THin;
+            const int wr = hx_div(pc, rd_twin), ci = pc - wr * TWin;
+            const int w_ = hx_div(wr, rd_thin), ri = wr - w_ * THin;
             const int gr = r0 + ri - (MASKED ? 0 : PAD_T), gc = c0 + ci - (MASKED ? 0 : PAD_L), gw = win0 + w_;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (gr >= 0 && gr < p.H && gw < p.B && gc >= 0 && gc < p.W) {
@@ -298,6 +316,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
             if (NGT > 1) issue(1);
         }
         __syncthreads();                                   // tile staged, weight group parked
+        if (tsp && tid == 0 && ch == 0) tsp[1] = wall_clock64();
         union U { uint4 u; f16x8 v; };
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
@@ -354,6 +373,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
         }
     }
     // ---- epilogue (see conv_f16x3_kernel) -------------------------------------------------------
+    if (tsp && tid == 0) tsp[2] = wall_clock64();
     if (tid < PCAP) {                                      // 2^-(sa + sw) of every output row's window
         const int wl = min(max(pos_win[tid] - win0, 0), HX_MAXWIN - 1);
         const int sa = (int)(__float_as_uint(win_is[wl]) >> 23) - 127;
@@ -362,9 +382,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     __syncthreads();
     float *tb = reinterpret_cast<float *>(in_lds) + wid * (16 * MS * HX_TPITCH);
     const int c4 = (lane & 7) * 4;
-    float4 s2v = make_float4(1.f, 1.f, 1.f, 1.f), t2v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.s2) s2v = *reinterpret_cast<const float4 *>(p.s2 + cout_off + c4);
-    if (p.t2) t2v = *reinterpret_cast<const float4 *>(p.t2 + cout_off + c4);
+    const float4 s2v = *reinterpret_cast<const float4 *>(bnp + 64 + c4), t2v = *reinterpret_cast<const float4 *>(bnp + 96 + c4);
     // D of a 16x16 MFMA: lane l holds rows 4*(l/16) + e, column l%16
     float osc[MS][4];                                  // 2^-(sa + sw) of this lane's rows
 #pragma unroll
@@ -373,8 +391,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
         for (int e = 0; e < 4; ++e) osc[ms][e] = pos_os[wid * (16 * MS) + ms * 16 + 4 * (lane >> 4) + e];
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
-        const int jn = cout_off + ns * 16 + (lane & 15);
-        const float s1 = p.s1[jn], t1 = p.t1[jn];
+        const float s1 = bnp[ns * 16 + (lane & 15)], t1 = bnp[32 + ns * 16 + (lane & 15)];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -448,4 +465,5 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
         __syncthreads();
         if (tid < p.NWIN && win0 + tid < p.B) atomicMax(reinterpret_cast<int *>(hs.amax_out) + win0 + tid, win_max[tid]);
     }
+    if (tsp && tid == 0) tsp[3] = wall_clock64();
 }

@@ -1083,7 +1083,7 @@ static void choose_tile_h(ConvOp &c) {
     const int nsteps = c.kh * c.kw / (NTh == 1 ? 2 : 1);
     const size_t wbytes = 2 * (size_t)std::min(4, nsteps) * HX_SLAB_BYTES;
     auto total = [&](size_t posbytes) {
-        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + wbytes + (size_t)pcap * 12 + (size_t)HX_MAXWIN * 8;
+        return std::max(posbytes, (size_t)HX_XCHG_BYTES) + wbytes + (size_t)pcap * 12 + (size_t)HX_MAXWIN * 8 + 512;      // + the slice's folded BN parameters
     };
     if (c.H * c.W <= 64) {
         const int nw = std::min(pcap / (c.H * c.W), HX_MAXWIN);
@@ -1138,9 +1138,37 @@ static int launch_convs_t(const ConvOp &c, ConvParams p, const float *amax_in, f
     p.tiles_h = (p.H + p.TH - 1) / p.TH; p.tiles_w = (p.W + p.TW - 1) / p.TW;
     const int groups = (p.B + p.NWIN - 1) / p.NWIN;
     const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
-    HxScale hs{amax_in, amax_out, c.sw};
+    HxScale hs{amax_in, amax_out, c.sw, nullptr};
+    static const bool want_ts = getenv("AMT_CONV_TS") != nullptr;      // diagnostic: phase split of a workgroup's life
+    static unsigned long long *ts_dev = nullptr;
+    static size_t ts_cap = 0;
+    const size_t nwg = (size_t)grid * c.nsliceh;
+    if (want_ts) {
+        if (nwg > ts_cap) {
+            if (ts_dev) (void)hipFree(ts_dev);
+            AMT_HIP_CHECK(hipMalloc(&ts_dev, nwg * 4 * sizeof(unsigned long long)));
+            ts_cap = nwg;
+        }
+        hs.ts = ts_dev;
+    }
     kern<<<dim3(grid, c.nsliceh), 1024 / MS, c.ldsh, st>>>(p, c.whs, hs);
     AMT_LAUNCH_CHECK();
+    if (want_ts) {
+        AMT_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(nwg * 4);
+        AMT_HIP_CHECK(hipMemcpy(h.data(), ts_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double a = 0, b = 0, e = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < nwg; ++i) {
+            a += (double)(h[4 * i + 1] - h[4 * i]); b += (double)(h[4 * i + 2] - h[4 * i + 1]);
+            e += (double)(h[4 * i + 3] - h[4 * i + 2]);
+            t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 3]);
+        }
+        fprintf(stderr, "conv_ts k%dx%d cin%d %dx%d masked%d wgs %zu: start->first MFMA %.2f us, MFMA loop %.2f us, epilogue %.2f us; "
+                        "kernel %.1f us = %.2f workgroup lives per slot of 512\n",
+                KH, KW, CIN, p.H, p.W, (int)MASKED, nwg, a / nwg / 100.0, b / nwg / 100.0, e / nwg / 100.0,
+                (double)(t1 - t0) / 100.0, (double)(t1 - t0) * 512.0 / ((a + b + e)));
+    }
     return AMT_OK;
 }
 template <int KH, int KW>
