@@ -382,6 +382,48 @@ def test_cqt_window_max(env, hop, L, grids):
         assert got[2] == 0.0
 
 
+def test_cqt_kernels_random_geometries(env):
+    """Seeded sweep of the block-sum CQT kernel over hops, lengths, grids and frame sets (both forms): every
+    combination against the oracle.  Geometry is where such a kernel breaks -- N_k below / above the hop, a multiple of
+    it, of 32; windows shorter than a filter; frames clustered, spread, repeated, missing."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr = 44100
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        hop = int(rng.choice([128, 256, 512, 1024]))
+        L = int(rng.integers(3 * hop, 90 * hop)) + int(rng.integers(0, hop))
+        T = 1 + L // hop
+        bpo = int(rng.choice([12, 24, 48]))
+        fmin = float(rng.choice([32.7, 110.0, 440.0, 1760.0]))
+        n_bins = int(rng.integers(3, 20))
+        t = np.arange(L) / sr
+        wave = np.stack([np.sin(2 * np.pi * fmin * 2 ** rng.uniform(0, 2) * t + rng.uniform(0, 6)) * np.exp(-rng.uniform(0, 4) * t)
+                         + 0.05 * rng.standard_normal(L) for _ in range(2)]).astype(np.float32)
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        if case == 3:
+            length = ((length + hop - 1) // hop * hop).astype(np.int32)         # every N_k a multiple of the hop
+        if case == 4:
+            length = ((length + 31) // 32 * 32 + 32).astype(np.int32)           # ... of 32
+        table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        if case in (3, 4):
+            lib = audio._lib.load()
+            len_d = torch.from_numpy(length).cuda()
+            coef = torch.empty((n_bins, 192), device='cuda')
+            audio._lib.check(lib.amt_cqt_coef(audio.ptr(table[0]), audio.ptr(len_d), n_bins, audio.ptr(coef), audio.stream_ptr()))
+            table = (table[0], len_d, coef)
+        wd = torch.from_numpy(wave).cuda()
+        got = audio.cqt_window_max(wd, table, hop).cpu().numpy()
+        for i in range(2):
+            ref = ocqt.cqt_window_max(wave[i], inc, length, hop)
+            assert abs(got[i] - ref) <= REL * ref, ('max', case, hop, L, bpo, fmin, i, got[i], ref)
+        src = np.stack([np.sort(rng.integers(0, T, 8)), np.clip(rng.integers(0, T) + np.arange(8) - 2, -1, T - 1)]).astype(np.int32)
+        src[0, rng.integers(0, 8)] = -1
+        out = audio.cqt_slices(wd, torch.from_numpy(src).cuda(), table, n_bins, hop).cpu().numpy()
+        for i in range(2):
+            ref = ocqt.cqt_frames(wave[i], src[i], inc, length, hop)
+            assert np.abs(out[i] - ref).max() <= REL * max(ref.max(), 1e-6), ('slices', case, hop, L, bpo, fmin, i)
+
+
 def test_cqt_window_max_whole_song(env):
     """A whole song as ONE signal (the reference's normalisers are maxima over the song's CQT, training.py:271-282):
     1700 hop-blocks do not fit the LDS, the block sums go through the HBM workspace.  Same oracle."""
