@@ -105,41 +105,62 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int Z, floa
 }
 
 // ---- im2col / col2im (Keras "same" padding: before = (k-1)/2, the rest after) -------------------
-__global__ void im2col_kernel(const float *__restrict__ x, size_t x_stride, int B, int H, int W, int C, int KH,
-                              int KW, float *__restrict__ col) {
-    const size_t K = (size_t)KH * KW * C;
-    const size_t total = (size_t)B * H * W * K;
+// One workgroup per output position (b, h, w): its K = KH KW C row is written contiguously, four channels per
+// lane and access where C allows (the index arithmetic is 32-bit and per tap, not 64-bit per element).
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, size_t x_stride, int B, int H, int W,
+                                                     int C, int KH, int KW, float *__restrict__ col) {
+    const int K = KH * KW * C;
     const int pt = (KH - 1) / 2, pl = (KW - 1) / 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t pos = i / K;
-        const int kk = (int)(i - pos * K);
-        const int ci = kk % C, tap = kk / C, dx = tap % KW, dy = tap / KW;
-        const int w = (int)(pos % W), h = (int)((pos / W) % H), b = (int)(pos / ((size_t)W * H));
-        const int hh = h + dy - pt, ww = w + dx - pl;
-        col[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[(size_t)b * x_stride + ((size_t)hh * W + ww) * C + ci] : 0.f;
-    }
-}
-// dX[b][h][w][ci] = sum over taps of dcol[(b, h - dy + pt, w - dx + pl)][(dy, dx, ci)]   (gather: no atomics)
-__global__ void col2im_kernel(const float *__restrict__ dcol, int B, int H, int W, int C, int KH, int KW,
-                              float *__restrict__ dx_) {
-    const size_t total = (size_t)B * H * W * C;
-    const size_t K = (size_t)KH * KW * C;
-    const int pt = (KH - 1) / 2, pl = (KW - 1) / 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % C);
-        const size_t pos = i / C;
-        const int w = (int)(pos % W), h = (int)((pos / W) % H), b = (int)(pos / ((size_t)W * H));
-        float s = 0.f;
-        for (int dy = 0; dy < KH; ++dy) {
-            const int ho = h - dy + pt;
-            if (ho < 0 || ho >= H) continue;
-            for (int dx = 0; dx < KW; ++dx) {
-                const int wo = w - dx + pl;
-                if (wo < 0 || wo >= W) continue;
-                s += dcol[(((size_t)b * H + ho) * W + wo) * K + ((size_t)dy * KW + dx) * C + ci];
+    const int npos = B * H * W;
+    for (int pos = blockIdx.x; pos < npos; pos += gridDim.x) {
+        const int w = pos % W, hb = pos / W, h = hb % H, b = hb / H;
+        const float *xb = x + (size_t)b * x_stride;
+        float *row = col + (size_t)pos * K;
+        if ((C & 3) == 0) {
+            const int C4 = C >> 2;
+            for (int q = threadIdx.x; q < (K >> 2); q += 256) {
+                const int tap = q / C4, c4 = q - tap * C4;
+                const int dy = tap / KW, dx = tap - dy * KW;
+                const int hh = h + dy - pt, ww = w + dx - pl;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)hh * W + ww) * C + 4 * c4);
+                *reinterpret_cast<float4 *>(row + 4 * q) = v;
+            }
+        } else {
+            for (int kk = threadIdx.x; kk < K; kk += 256) {
+                const int tap = kk / C, ci = kk - tap * C;
+                const int dy = tap / KW, dx = tap - dy * KW;
+                const int hh = h + dy - pt, ww = w + dx - pl;
+                row[kk] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xb[((size_t)hh * W + ww) * C + ci] : 0.f;
             }
         }
-        dx_[i] = s;
+    }
+}
+// dX[b][h][w][ci] = sum over taps of dcol[(b, h - dy + pt, w - dx + pl)][(dy, dx, ci)]   (gather: no atomics).
+// A workgroup takes 256 / min(C, 256) input positions at a time, lanes over channels, taps in a fixed order.
+__global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ dcol, int B, int H, int W, int C, int KH,
+                                                     int KW, float *__restrict__ dx_) {
+    const int K = KH * KW * C;
+    const int pt = (KH - 1) / 2, pl = (KW - 1) / 2;
+    const int npos = B * H * W;
+    const int cw = min(C, 256), ppw = 256 / cw;            // channels per pass of a position, positions per workgroup
+    const int sub = threadIdx.x / cw, c0 = threadIdx.x - sub * cw;
+    for (int pos = blockIdx.x * ppw + sub; pos < npos && sub < ppw; pos += gridDim.x * ppw) {
+        const int w = pos % W, hb = pos / W, h = hb % H, b = hb / H;
+        for (int ci = c0; ci < C; ci += cw) {
+            float s = 0.f;
+            for (int dy = 0; dy < KH; ++dy) {
+                const int ho = h - dy + pt;
+                if (ho < 0 || ho >= H) continue;
+                for (int dx = 0; dx < KW; ++dx) {
+                    const int wo = w - dx + pl;
+                    if (wo < 0 || wo >= W) continue;
+                    s += dcol[(((size_t)b * H + ho) * W + wo) * K + (dy * KW + dx) * C + ci];
+                }
+            }
+            dx_[(size_t)pos * C + ci] = s;
+        }
     }
 }
 
@@ -637,7 +658,7 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
             const int Kc = o.kh * o.kw * o.Cin;
             const float *A = in.v;
             if (!(o.kh == 1 && o.kw == 1)) {
-                im2col_kernel<<<grid1(M * Kc), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
+                im2col_kernel<<<(unsigned)std::min<size_t>(M, 1u << 20), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
                 A = t->col;
             }
             rc = gemm(t, false, false, A, Kc, t->params[o.p0].w, o.Cout, out.v, o.Cout, (int)M, o.Cout, Kc, t->params[o.p1].w, st);
@@ -765,7 +786,7 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
             const bool one = o.kh == 1 && o.kw == 1;
             const float *A = in.v;
             if (!one) {
-                im2col_kernel<<<grid1(M * Kc), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
+                im2col_kernel<<<(unsigned)std::min<size_t>(M, 1u << 20), 256, 0, st>>>(in.v, (size_t)o.H * o.W * o.Cin, B, o.H, o.W, o.Cin, o.kh, o.kw, t->col);
                 A = t->col;
             }
             rc = gemm(t, true, false, A, Kc, out.g, o.Cout, t->params[o.p0].g, o.Cout, Kc, o.Cout, (int)M, nullptr, st);
@@ -785,7 +806,7 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
                 if (!inT.g_set) { dst = inT.g; }
                 else if ((size_t)B * out.H * out.W * out.C >= nin) dst = out.g;
                 else return AMT_E_NOMEM;
-                col2im_kernel<<<grid1(nin), 256, 0, st>>>(t->col, B, o.H, o.W, o.Cin, o.kh, o.kw, dst);
+                col2im_kernel<<<(unsigned)std::min<size_t>(M, 1u << 20), 256, 0, st>>>(t->col, B, o.H, o.W, o.Cin, o.kh, o.kw, dst);
                 rc = give_grad(t, o.in0, dst, nin, st);
             }
             if (rc != AMT_OK) return rc;
