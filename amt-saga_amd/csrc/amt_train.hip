@@ -33,7 +33,7 @@ typedef float tf32x16 __attribute__((ext_vector_type(16)));
 #define TR_BN_MOMENTUM 0.99f
 #define TG_TM 64
 #define TG_TN 64
-#define TG_KC 16
+#define TG_KC 32
 
 // ---- GEMM: C[M][N] = sum_k A(m,k) B(k,n) (+ bias[n]); A stored [M][lda] (or [K][lda] when TA),
 //      B stored [K][ldb] (or [N][ldb] when TB).  gridDim.z slices of the contraction write partial
@@ -53,29 +53,47 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A,
     tf32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += TG_KC) {
-        __syncthreads();
+    constexpr int NA = (TG_TM * TG_KC) / 256, NB = (TG_KC * TG_TN) / 256;
+    float ra[NA], rb[NB];
+    // the next k-step's tiles are requested before this step's MFMAs and parked in LDS after them: the global
+    // latency runs under the matrix work instead of in front of it
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < (TG_TM * TG_KC) / 256; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
             int r, c;
             if (TA) { c = idx / TG_TM; r = idx - c * TG_TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
             const int m = m0 + r, k = k0 + c;
-            float v = 0.f;
-            if (m < M && k < kend) v = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
-            As[r][c] = v;
+            ra[i] = (m < M && k < kend) ? (TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < (TG_KC * TG_TN) / 256; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int idx = tid + i * 256;
             int c, j;
             if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TG_TN; j = idx - c * TG_TN; }
             const int k = k0 + c, n = n0 + j;
-            float v = 0.f;
-            if (n < N && k < kend) v = TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
-            Bs[c][j] = v;
+            rb[i] = (n < N && k < kend) ? (TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TG_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + i * 256;
+            int r, c;
+            if (TA) { c = idx / TG_TM; r = idx - c * TG_TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
+            As[r][c] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            int c, j;
+            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TG_TN; j = idx - c * TG_TN; }
+            Bs[c][j] = rb[i];
         }
         __syncthreads();
+        if (k0 + TG_KC < kend) gload(k0 + TG_KC);
 #pragma unroll
         for (int kk = 0; kk < TG_KC; kk += 2) {
             const float a = As[mi * 32 + (lane & 31)][kk + (lane >> 5)];
