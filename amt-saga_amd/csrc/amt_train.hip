@@ -184,20 +184,21 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ d
 
 // ---- column reductions over a [M][C] matrix: two stages, fixed order ---------------------------------
 // mode 0 / 3: sum x;  1: sum (x - mu[c])^2;  2: (sum dy, sum dy * zhat) with zhat = (z - mu) * inv
-#define CR_SPLIT 64
+#define CR_SPLIT 512                      // most row splits of a column reduction (the launcher picks 8 .. CR_SPLIT from M)
 __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict__ x, const float *__restrict__ z,
                                                          const float *__restrict__ mu, const float *__restrict__ inv,
-                                                         size_t M, int C, int mode, float *__restrict__ part0,
-                                                         float *__restrict__ part1) {
+                                                         size_t M, int C, int mode, int nsplit,
+                                                         float *__restrict__ part0, float *__restrict__ part1) {
     // block = 8 row-lanes x 32 channels; blockIdx.x = channel block, blockIdx.y = row split
     __shared__ float red0[8][33], red1[8][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    const size_t rows = (M + CR_SPLIT - 1) / CR_SPLIT;
+    const size_t rows = (M + nsplit - 1) / nsplit;
     const size_t r0 = (size_t)blockIdx.y * rows, r1 = min(M, r0 + rows);
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
         const float m = (mode >= 1 && mu) ? mu[c] : 0.f, iv = mode == 2 ? inv[c] : 0.f;
+#pragma unroll 4
         for (size_t r = r0 + rl; r < r1; r += 8) {
             const float v = x[r * C + c];
             if (mode == 0 || mode == 3) s0 += v;
@@ -216,12 +217,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
 }
 // mode 0 -> out0 = sum / M (mean);  mode 1 -> out0 = var = sum / M, out1 = 1/sqrt(var + eps);
 // mode 2 -> out0 = sum dy, out1 = sum dy zhat;  mode 3 -> out0 = plain sum
-__global__ void colreduce_final_kernel(const float *__restrict__ part0, const float *__restrict__ part1, int C,
-                                       float invM, int mode, float *__restrict__ out0, float *__restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// One workgroup per 32 channels: eight row-lanes add nsplit / 8 partials each (fixed order), LDS combines them.
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float *__restrict__ part0, const float *__restrict__ part1,
+                                                               int C, float invM, int mode, int nsplit,
+                                                               float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ float red0[8][33], red1[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < CR_SPLIT; ++s) { a += part0[(size_t)s * C + c]; if (mode == 2) b += part1[(size_t)s * C + c]; }
+    if (c < C)
+        for (int s = rl; s < nsplit; s += 8) { a += part0[(size_t)s * C + c]; if (mode == 2) b += part1[(size_t)s * C + c]; }
+    red0[rl][cl] = a; red1[rl][cl] = b;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    a = 0.f; b = 0.f;
+    for (int i = 0; i < 8; ++i) { a += red0[i][cl]; b += red1[i][cl]; }
     if (mode == 0) out0[c] = a * invM;
     else if (mode == 1) { const float v = a * invM; out0[c] = v; out1[c] = 1.0f / sqrtf(v + TR_BN_EPS); }
     else if (mode == 2) { out0[c] = a; out1[c] = b; }
@@ -475,8 +485,11 @@ int gemm(amt_trainer *t, bool TA, bool TB, const float *A, int lda, const float 
 
 int colreduce(amt_trainer *t, const float *x, const float *z, const float *mu, const float *inv, size_t M, int C, int mode,
               float *out0, float *out1, hipStream_t st) {
-    colreduce_kernel<<<dim3((C + 31) / 32, CR_SPLIT), 256, 0, st>>>(x, z, mu, inv, M, C, mode, t->red0, t->red1);
-    colreduce_final_kernel<<<(C + 63) / 64, 64, 0, st>>>(t->red0, t->red1, C, 1.0f / (float)M, mode, out0, out1);
+    // ~64 rows per row-lane and split, between 8 splits and enough workgroups to cover the chip twice
+    int nsplit = (int)std::min<size_t>(CR_SPLIT, std::max<size_t>(8, M / 512));
+    nsplit = (nsplit + 7) & ~7;
+    colreduce_kernel<<<dim3((C + 31) / 32, nsplit), 256, 0, st>>>(x, z, mu, inv, M, C, mode, nsplit, t->red0, t->red1);
+    colreduce_final_kernel<<<(C + 31) / 32, 256, 0, st>>>(t->red0, t->red1, C, 1.0f / (float)M, mode, nsplit, out0, out1);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
