@@ -38,22 +38,25 @@ typedef float tf32x16 __attribute__((ext_vector_type(16)));
 // ---- GEMM: C[M][N] = sum_k A(m,k) B(k,n) (+ bias[n]); A stored [M][lda] (or [K][lda] when TA),
 //      B stored [K][ldb] (or [N][ldb] when TB).  gridDim.z slices of the contraction write partial
 //      tiles to `part` ([z][M][N]); splitk_reduce_kernel adds them in z order.
-template <bool TA, bool TB>
+// WN = 2: 64 x 64 tile, waves 2 x 2;  WN = 1: 128 x 32 tile, waves 4 x 1 (the convolutions' N is 32 channels half
+// of the time: a 64-wide tile would leave every second MFMA column block empty)
+template <bool TA, bool TB, int WN>
 __global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A, int lda,
                                                      const float *__restrict__ B, int ldb,
                                                      float *__restrict__ C, int ldc, int M, int N, int K,
                                                      int kslice, const float *__restrict__ bias,
                                                      float *__restrict__ part) {
-    __shared__ float As[TG_TM][TG_KC + 1];
-    __shared__ float Bs[TG_KC][TG_TN + 1];
+    constexpr int TM = 32 * (4 / WN), TN = 32 * WN;
+    __shared__ float As[TM][TG_KC + 1];
+    __shared__ float Bs[TG_KC][TN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int m0 = blockIdx.y * TG_TM, n0 = blockIdx.x * TG_TN;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int kbeg = blockIdx.z * kslice, kend = min(K, kbeg + kslice);
-    const int mi = wid >> 1, ni = wid & 1;
+    const int mi = WN == 2 ? wid >> 1 : wid, ni = WN == 2 ? wid & 1 : 0;
     tf32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    constexpr int NA = (TG_TM * TG_KC) / 256, NB = (TG_KC * TG_TN) / 256;
+    constexpr int NA = (TM * TG_KC) / 256, NB = (TG_KC * TN) / 256;
     float ra[NA], rb[NB];
     // the next k-step's tiles are requested before this step's MFMAs and parked in LDS after them: the global
     // latency runs under the matrix work instead of in front of it
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A,
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
             int r, c;
-            if (TA) { c = idx / TG_TM; r = idx - c * TG_TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
+            if (TA) { c = idx / TM; r = idx - c * TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
             const int m = m0 + r, k = k0 + c;
             ra[i] = (m < M && k < kend) ? (TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
         }
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A,
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + i * 256;
             int c, j;
-            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TG_TN; j = idx - c * TG_TN; }
+            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TN; j = idx - c * TN; }
             const int k = k0 + c, n = n0 + j;
             rb[i] = (n < N && k < kend) ? (TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
         }
@@ -82,14 +85,14 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const float *__restrict__ A,
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
             int r, c;
-            if (TA) { c = idx / TG_TM; r = idx - c * TG_TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
+            if (TA) { c = idx / TM; r = idx - c * TM; } else { r = idx / TG_KC; c = idx - r * TG_KC; }
             As[r][c] = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + i * 256;
             int c, j;
-            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TG_TN; j = idx - c * TG_TN; }
+            if (TB) { j = idx / TG_KC; c = idx - j * TG_KC; } else { c = idx / TN; j = idx - c * TN; }
             Bs[c][j] = rb[i];
         }
         __syncthreads();
@@ -457,7 +460,9 @@ int new_tensor(amt_trainer *t, int H, int W, int C, bool flat = false) {
 // GEMM dispatch with split over the contraction when the output grid is small
 int gemm(amt_trainer *t, bool TA, bool TB, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
          int M, int N, int K, const float *bias, hipStream_t st) {
-    const int gx = (N + TG_TN - 1) / TG_TN, gy = (M + TG_TM - 1) / TG_TM;
+    const int wn = N <= 32 ? 1 : 2;
+    const int tm = 32 * (4 / wn), tn = 32 * wn;
+    const int gx = (N + tn - 1) / tn, gy = (M + tm - 1) / tm;
     int Z = 1;
     const long tiles = (long)gx * gy;
     if (tiles < 512 && K > 4 * TG_KC) Z = (int)std::min<long>((512 + tiles - 1) / tiles, (K + 4 * TG_KC - 1) / (4 * TG_KC));
@@ -474,7 +479,11 @@ int gemm(amt_trainer *t, bool TA, bool TB, const float *A, int lda, const float 
         part = t->part;
     }
     dim3 grid(gx, gy, Z);
-#define TG_LAUNCH(ta, tb) tgemm_kernel<ta, tb><<<grid, 256, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kslice, bias, part)
+#define TG_LAUNCH(ta, tb)                                                                                       \
+    do {                                                                                                        \
+        if (wn == 1) tgemm_kernel<ta, tb, 1><<<grid, 256, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kslice, bias, part); \
+        else tgemm_kernel<ta, tb, 2><<<grid, 256, 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, kslice, bias, part);  \
+    } while (0)
     if (TA && TB) return AMT_E_UNSUPPORTED;
     if (TA) TG_LAUNCH(true, false); else if (TB) TG_LAUNCH(false, true); else TG_LAUNCH(false, false);
 #undef TG_LAUNCH
