@@ -11,6 +11,24 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// the same with v_mfma_f32_32x32x16_f16 (twice the flops per operand byte read from the register file)
+__global__ __launch_bounds__(256) void mfma_loop32(const h8 *__restrict__ a_in, const h8 *__restrict__ b_in, float *out, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    h8 a0 = a_in[t], b0 = b_in[t], a1 = a_in[t ^ 1], b1 = b_in[t ^ 1];
+    f16v c0 = {0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, c3, 0, 0, 0);
+    }
+    const f16v s = c0 + c1 + c2 + c3;
+    float r = 0.f;
+    for (int e = 0; e < 16; ++e) r += s[e];
+    out[t] = r;
+}
 
 __global__ __launch_bounds__(256) void mfma_loop(const h8 *__restrict__ a_in, const h8 *__restrict__ b_in, float *out, int iters) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,6 +93,25 @@ int main() {
                    data ? "random operands" : "zero operands", wps, sum / reps, best, reps,
                    (double)blocks * 4 * iters * 8 * (2.0 * 16 * 16 * 32) / (best * 1e12) * 1e3);
         }
+    }
+    for (int data = 0; data < 2; ++data) {
+        const int wps = 4, blocks = cus * wps, it32 = iters;     // 4 x (2 x 32*32*16) per iteration = the same flops as 8 x 16x16x32
+        const h8 *src = data ? ar : az;
+        mfma_loop32<<<blocks, 256>>>(src, src, out, 2000);
+        CK(hipDeviceSynchronize());
+        float best = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0));
+            mfma_loop32<<<blocks, 256>>>(src, src, out, it32);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double fl = (double)blocks * 4 * it32 * 4 * (2.0 * 32 * 32 * 16);
+            const float tf = (float)(fl / (ms * 1e-3) / 1e12);
+            best = tf > best ? tf : best;
+        }
+        printf("32x32x16: %-18s %d wave(s)/SIMD: %7.1f TFLOP/s best of 3\n", data ? "random operands" : "zero operands", wps, best);
     }
     return 0;
 }
