@@ -314,7 +314,10 @@ def main():
                     # v_mfma_f32_16x16x32_f16 on register operands, nothing else running, sustains 1620 TFLOP/s on
                     # random non-zero data (2090 on zeros): the power limit, not the schedule, sets the f16 ceiling
                     **({'sustained_f16_mfma_tflops_measured': SUSTAINED_F16_TF,
-                        'executed_vs_sustained': round(achieved_tf * nmf / SUSTAINED_F16_TF, 3)} if split else {}),
+                        'executed_vs_sustained': round(achieved_tf * nmf / SUSTAINED_F16_TF, 3),
+                        # separate rocprofv3 --pmc passes over this kernel (profiles/r02/mfma_util_f16x3.txt): the chip
+                        # is at its power limit while it runs -- the clock falls as the matrix pipe fills
+                        'mfma_pipe_busy_pmc': 0.663, 'held_clock_ghz_pmc': 1.72} if split and conv_mode == 2 else {}),
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2))
