@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 with the driver contract plus
                 and a multiprocessing Pool (one window per task, one BLAS thread each: the reference's
                 worker model, training.py:623-630)
   value_f32_mfma          the same step with the strict-f32 convolutions (--conv-mode 0), same run
+  value_timing_on_two_streams   the same step with timing_end on a second stream (AMT_TIMING_STREAMS=2)
   value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
                           (SURVEY 8d defines the metric including that copy; never `value`)
   value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
@@ -361,6 +362,17 @@ def main():
             extras['value_f32_mfma'] = round(B * world * k0 / dt0, 2)
             for n in loop.nets.values():
                 n.set_mode(conv_mode)
+            step()
+        # (1b) timing_end on a second stream under timing_start (TranscriptionLoop.timing_streams = 2, opt-in: it fills
+        # the tails of the small-image launches, but two kernels then share the chip and a kernel's own duration --
+        # the roofline's denominator -- is no longer defined; so it is an extra leg, not the default)
+        if 'timing' in wl['heads'] and loop.timing_streams == 1:
+            loop.timing_streams = 2
+            step()
+            kt = max(1, min(args.steps, 3))
+            dtt, _ = timed_steps(kt, step)
+            extras['value_timing_on_two_streams'] = round(B * world * kt / dtt, 2)
+            loop.timing_streams = 1
             step()
         # (2) host -> HBM copy of the batch's audio inside the timed region (pinned host memory, one copy
         # per step on the launch stream, no overlap with compute)
