@@ -20,11 +20,15 @@ def env_world():
             int(os.environ.get('LOCAL_RANK', 0)))
 
 
-def init(backend=None):
+def init(backend=None, force=False):
     """Initialise torch.distributed from the torchrun environment (no-op for a
-    single process).  Returns (rank, world, local_rank)."""
+    single process unless force=True or AMT_DIST_FORCE=1: then a world of ONE rank
+    still creates the process group, so that the RCCL communicator, the device-tensor
+    all-gather and the reductions below execute on a one-GPU box).
+    Returns (rank, world, local_rank)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get('AMT_DIST_FORCE') == '1'
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -56,7 +60,7 @@ def gather_events(events, n_total=None):
     and trimmed afterwards.  Returns int32 [sum n_local, 7] sorted by
     (window, iter) -- identical for every world size (determinism check)."""
     ev = events.reshape(-1, events.shape[-1]).contiguous()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         out = ev
     else:
         world = dist.get_world_size()
@@ -87,7 +91,7 @@ def barrier():
 
 def max_over_ranks(x, device=None):
     """MAX-reduce a python float over ranks (bench timing contract)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(x)
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if (
@@ -98,7 +102,7 @@ def max_over_ranks(x, device=None):
 
 
 def sum_over_ranks(x, device=None):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(x)
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if (

@@ -13,8 +13,9 @@
 // Conv kernel (Cin multiple of 32): one 256-thread workgroup computes
 // 128*MT output positions x Cout channels.  GEMM view: M = positions,
 // N = Cout, K = (dy, dx, cin).  v_mfma_f32_32x32x2_f32 (f32 in, f32 acc: a
-// k-ordered fmaf chain, bitwise) -- the contraction the north star puts on
-// MFMA while keeping float parity with the CPU.
+// k-ordered fmaf chain per (tap, 32-channel chunk), the chunks' sums added in
+// tap order) -- the contraction the north star puts on MFMA while keeping
+// float parity with the CPU.
 //   * the input tile incl. the conv halo (explicit zeros = Keras "same"
 //     padding, asymmetric for even kernels) is staged once per 32-channel
 //     chunk into LDS as [pos][33] (pad 1 float: A-fragment reads hit 32
@@ -158,6 +159,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 }
                 const int tapoff = (dy * TWin + dx) * RD_CSTRIDE;
                 const float *wb = wbuf + cur * WSLAB + ((lane >> 5) * 32 + (lane & 31)) * NT;
+                // blocked summation: the 32 products of one (tap, chunk) go through a fresh accumulator (an fmaf
+                // chain of length 32 inside the matrix pipe) which is then added to the running sum -- 64 + 32
+                // roundings on the critical path of a K = 2048 contraction instead of 2048.  A single chain over
+                // all of K (round 1-2) sat 11x farther from the float64 result than numpy's blocked GEMM on the
+                // timing head at N = 2048 (profiles/r02/rdcnn_error_vs_f64.json); OpenBLAS blocks K the same way.
+                f32x16 part[MT][NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) part[mt][nt][e] = 0.f;
 #pragma unroll
                 for (int cp = 0; cp < RD_CC / 2; ++cp) {
                     float a[MT];
@@ -178,9 +191,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                a[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                            part[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a[mt], bfr[nt], part[mt][nt], 0, 0, 0);
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[mt][nt][e] = __fadd_rn(acc[mt][nt][e], part[mt][nt][e]);
                 if (more) {
                     float4 *dst = reinterpret_cast<float4 *>(wbuf + (cur ^ 1) * WSLAB);
 #pragma unroll

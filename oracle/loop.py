@@ -56,30 +56,67 @@ class LoopOracle:
             self.bank_frames = self.bank_mag[0].shape[1]
         self.tail_frames = int(TAIL_SECONDS * p.sr / p.H)
         self.margins = []        # |frac - 0.5| of every rounded decision (near-tie reporting)
+        # per-decision record of the last run_window(): (name, iteration, float value(s), margin, decided, forced)
+        self.decisions = []
+        self._force = None       # see run_window(force=...)
+        self._it = 0
 
     def _predict(self, name, cfgname, x):
         y = orc.forward(self.w[name], self.cfg[cfgname], [np.asarray(x, np.float32)[None, :, :, None]],
                         self.dtype)
         return y[0]
 
-    def _round(self, y, lo, hi):
-        self.margins.append(abs(float(y) - np.floor(float(y)) - 0.5))
-        return rint_clamp(y, lo, hi)
+    def _round(self, y, lo, hi, name='', col=None):
+        margin = abs(float(y) - np.floor(float(y)) - 0.5)
+        self.margins.append(margin)
+        v = rint_clamp(y, lo, hi)
+        forced = False
+        if self._force is not None and col is not None:
+            # teacher forcing at a near-tie: when this float sits within `band` of a rounding boundary the two
+            # arithmetics may legitimately land on different sides; the run then continues with the decision
+            # handed in (the product's), provided it is the integer on the other side of that boundary -- so
+            # every later iteration of the window is still compared like any other
+            ev, band = self._force
+            g = int(ev[self._it][col])
+            if g != v and margin < band.get(name, 0.0) and abs(g - v) == 1:
+                v, forced = g, True
+        self.decisions.append((name, self._it, float(y), margin, v, forced))
+        return v
 
-    def run_window(self, wave, refs, window_id=0):
+    def _argmax(self, pr, name='instrument', col=3):
+        pr = np.asarray(pr)
+        v = int(np.argmax(pr))
+        top = np.sort(pr)[-2:]
+        margin = float(top[1] - top[0])
+        forced = False
+        if self._force is not None:
+            ev, band = self._force
+            g = int(ev[self._it][col])
+            if g != v and margin < band.get(name, 0.0) and 0 <= g < len(pr) and pr[v] - pr[g] < band.get(name, 0.0):
+                v, forced = g, True
+        self.decisions.append((name, self._it, pr.copy(), margin, v, forced))
+        return v
+
+    def run_window(self, wave, refs, window_id=0, force=None):
         """wave float32 [L]; refs dict(ref_mag, ref_C_1, ref_C_inst, ref_C_foc).
+        force: None, or (events [iters, 7] of another implementation, {head name: tie band in output units}):
+        decisions whose float lies within the band of a rounding tie adopt that implementation's integer (see
+        _round).  self.decisions then lists every decision with its float, margin and whether it was forced.
         Returns (events [iters, 7] int32, residual magnitude [F, T] float32)."""
         p = self.p
+        self._force = force
+        self.decisions = []
         ac = oa.AudioCompleteOracle(np.asarray(wave, np.float32), p.N, p.H)
         ac.mag                                        # STFT + magphase (training.py:269)
         T = ac.shape[1]
         events = np.full((self.iters, 7), -1, np.int32)
         for it in range(self.iters):
+            self._it = it
             if 'timing' in self.heads:
                 ct = oa.AudioCompleteOracle.compress_bands(ac.mag, bands=p.timing_bands)
                 ct = oa.AudioCompleteOracle._resize(ct, p.timing_frames) / refs['ref_mag']
-                onset = self._round(self._predict('timing_start', 'timing', ct)[0], 0, T - 1)
-                end = self._round(self._predict('timing_end', 'timing', ct)[0], 0, T)
+                onset = self._round(self._predict('timing_start', 'timing', ct)[0], 0, T - 1, 'timing_start', 5)
+                end = self._round(self._predict('timing_end', 'timing', ct)[0], 0, T, 'timing_end', 6)
             else:
                 onset, end = 0, p.pitch_frames
             src = ocqt.slice_C_frames(T, onset, end, p.pitch_frames)
@@ -88,15 +125,15 @@ class LoopOracle:
             pitch, program, velocity = 60, -1, -1
             if 'pitch' in self.heads:
                 cp = ocqt.cqt_frames(wf, src, self.tab_pitch[0], self.tab_pitch[1], p.H) / refs['ref_C_1']
-                pitch = self._round(self._predict('pitch', 'pitch', cp)[0], p.pitch_low, p.pitch_high)
+                pitch = self._round(self._predict('pitch', 'pitch', cp)[0], p.pitch_low, p.pitch_high, 'pitch', 2)
             if 'instrument' in self.heads:
                 ci = ocqt.cqt_frames(wf, src, self.tab_inst[0], self.tab_inst[1], p.H) / refs['ref_C_inst']
-                program = int(np.argmax(self._predict('instrument', 'instrument', ci)))
+                program = self._argmax(self._predict('instrument', 'instrument', ci))
             if 'velocity' in self.heads:
                 b0 = self.vel_bpt * (pitch - p.pitch_low)
                 cv = ocqt.cqt_frames(wf, src, self.tab_vel[0][b0:b0 + p.bins_velocity],
                                      self.tab_vel[1][b0:b0 + p.bins_velocity], p.H) / refs['ref_C_foc']
-                velocity = self._round(self._predict('velocity', 'velocity', cv)[0], 1, 127)
+                velocity = self._round(self._predict('velocity', 'velocity', cv)[0], 1, 127, 'velocity', 4)
             if self.do_subtract:
                 n_pitch = p.pitch_high - p.pitch_low + 1
                 pr = min(max(program, 0), p.instrument_classes - 1) if program >= 0 else 0

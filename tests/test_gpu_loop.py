@@ -34,22 +34,48 @@ def test_glue_kernels(env):
         assert np.array_equal(tab[i], slice_C_frames(T, int(s[i]), int(e[i]), 8)), i
 
 
-TIE = 0.02      # a rounded decision closer than this to a rounding tie (in output units) is reported, not compared
+# Near-tie policy and the per-window comparison: oracle/compare.py (shared with test_gpu_synth and smoke()).
+import os
+from oracle.compare import bands_for, compare_windows
+DIFFS = {}       # head -> list of |gpu float - oracle float|, all cases of this module
+# AMT_TEST_BAND_SCALE widens the bands for a measurement run (the diffs are still recorded): how FLOAT_TOL was set
+BAND_SCALE = float(os.environ.get('AMT_TEST_BAND_SCALE', '1'))
 
 
-def _run_case(env, p, heads, iters, B, seed, groups=(0,), subtract=True, tweak=None, max_onset=0.4, guess='bank'):
-    """Product loop vs oracle loop on B windows.  Returns (events, n_checked, n_skipped)."""
+@pytest.fixture(scope='module', autouse=True)
+def _dump_diffs():
+    import json, os
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    summary = {k: dict(n=len(v), max=float(np.max(v)), p99=float(np.percentile(v, 99)), median=float(np.median(v)))
+               for k, v in DIFFS.items() if len(v)}
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'loop_float_diffs.json'), 'w') as f:
+            json.dump(summary, f, indent=1)
+    except OSError:
+        pass
+    print('loop float diffs (output units):', summary)
+
+
+def _run_case(env, p, heads, iters, B, seed, groups=(0,), subtract=True, tweak=None, max_onset=0.4, guess='bank',
+              notes=(1, 3)):
+    """Product loop vs oracle loop on B windows; EVERY window is compared.  Returns
+    (events, n_clean, n_tie, ...): n_clean windows had no decision inside the tie band, n_tie had at least one
+    (and were still compared in full, with that decision handed to the oracle when the two sides differ)."""
     torch, synth = env['torch'], env['synth']
     lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, subtract=subtract, guess=guess)
     if tweak:
         tweak(lp)
     lp.setup_device()
     L = p.H * (p.timing_frames - 1)
-    wave, _ = synth.make_windows(B, L, seed=seed, notes_per_window=(1, 3), groups=groups,
+    wave, _ = synth.make_windows(B, L, seed=seed, notes_per_window=notes, groups=groups,
                                  max_onset=max_onset * p.window_size_note_time, device='cuda')
+    lp.trace = []
     events, b = lp.run(wave, window0=100)
+    trace, lp.trace = [{k: v.cpu().numpy() for k, v in t.items()} for t in lp.trace], None
     ev = events.cpu().numpy()
-    assert ev.shape == (iters, B, 7)
+    assert ev.shape == (iters, B, 7) and len(trace) == iters
     from oracle import synth as osynth
     bank = osynth.guess_bank_waves(groups, p.pitch_low, p.pitch_high, sr=p.sr) if subtract else None
     remap = np.zeros(3, np.int32)
@@ -59,25 +85,15 @@ def _run_case(env, p, heads, iters, B, seed, groups=(0,), subtract=True, tweak=N
                                   subtract=subtract,
                                   prog_group=remap[synth.prog_group_table(p.instrument_classes)],
                                   bank_waves=bank)
-    F = p.N // 2 + 1
-    checked = skipped = 0
+    bands = bands_for(p, BAND_SCALE)
     wave_h = wave.cpu().numpy()
-    mags = b.mag.cpu().numpy()
-    for i in range(B):
-        refs = {k: v[i].item() for k, v in lp.refs.items()}
-        orc.margins = []
-        ev_ref, mag_ref = orc.run_window(wave_h[i], refs, 100 + i)
-        if orc.margins and min(orc.margins) < TIE:
-            skipped += 1                               # a rounding near-tie: reported, not failed
-            continue
-        checked += 1
-        assert np.array_equal(ev[:, i, :], ev_ref), (i, ev[:, i, :], ev_ref)
-        mag = mags[i][:, :F].T
-        assert np.abs(mag - mag_ref).max() / mag_ref.max() < 1e-4
-        assert abs(float(b.ref_max[i]) - mag_ref.max()) / mag_ref.max() < 1e-4
-    print('loop parity %s iters %d: %d windows bit-exact, %d skipped as near-ties (< %.2f of a rounding tie)' %
-          ('+'.join(heads), iters, checked, skipped, TIE))
-    return ev, checked, skipped, lp, orc, wave_h
+    clean, ties, forced = compare_windows(orc, wave_h, {k: v.cpu().numpy() for k, v in lp.refs.items()}, ev, trace,
+                                          b.mag.cpu().numpy(), b.ref_max.cpu().numpy(), bands, window0=100,
+                                          diffs=DIFFS)
+    print('loop parity %s iters %d: %d windows compared in full (events bit-exact, floats within the band, residual '
+          '1e-4): %d with no decision near a tie, %d with one inside the band (%d decisions handed over)' %
+          ('+'.join(heads), iters, B, clean, ties, forced))
+    return ev, clean, ties, lp, orc, wave_h
 
 
 def _distinct(ev, col):
@@ -91,10 +107,9 @@ def test_loop_32_windows_distinct_decisions(env):
     statement about 32 different functions values per head, not about a constant."""
     p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)             # 86 frames: oracle-sized
     ev, checked, skipped, lp, orc, wave_h = _run_case(env, p, ('timing', 'pitch', 'velocity'), 2, 32, seed=21)
-    # 2 iterations x (onset, end, pitch, velocity) = 8 rounded decisions per window, each within TIE of a rounding
-    # boundary with probability 2 TIE = 0.04: 1 - 0.96^8 = 28 % of the windows (9 of 32) are expected to be
-    # near-ties of the f64 oracle itself and are reported instead of compared
-    assert checked >= 20, (checked, skipped)
+    # all 32 windows are compared (_run_case); with bands of ~1e-3 of an output unit and 8 rounded decisions per
+    # window at most a window or two are expected to have a decision inside a band at all
+    assert checked >= 29, (checked, skipped)
     assert _distinct(ev, 5) >= 10 and _distinct(ev, 6) >= 10      # onset / end frames
     assert _distinct(ev, 2) >= 10 and _distinct(ev, 4) >= 8       # pitch / velocity
     # song-level constants: the product's prepare() vs the oracle's definition
@@ -124,7 +139,7 @@ def _shift_end(delta):
 def test_loop_vs_oracle(env, heads, iters, B, nfft, wsec, groups, tweak, what):
     p = env['hp'].Hyperparams(N=nfft, window_size_note_time=wsec)
     ev, checked, skipped, lp, orc, _ = _run_case(env, p, heads, iters, B, seed=21 + iters, groups=groups, tweak=tweak)
-    assert checked >= max(2, B // 2), (what, checked, skipped)
+    assert checked + skipped == B and checked >= B - 2, (what, checked, skipped)
     if 'tile rule' in what:
         d = ev[0, :, 6] - ev[0, :, 5]
         assert np.any((d >= 3) & (d < 8)), d
@@ -137,7 +152,7 @@ def test_loop_without_subtraction_c2_shape(env):
     with the oracle and the magnitudes are left untouched."""
     p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
     ev, checked, skipped, lp, orc, _ = _run_case(env, p, ('pitch',), 1, 12, seed=2, subtract=False)
-    assert checked >= 8
+    assert checked >= 11
     assert _distinct(ev, 2) >= 4
     assert np.all(ev[..., 3] == -1) and np.all(ev[..., 4] == -1)           # no instrument / velocity head
 
@@ -147,7 +162,18 @@ def test_loop_full_size_c3_vs_oracle(env):
     one subtraction -- against the oracle loop: events bit-exact, residual within 1e-4."""
     p = env['hp'].Hyperparams(N=2048)
     ev, checked, skipped, lp, orc, _ = _run_case(env, p, ('timing', 'pitch', 'velocity'), 1, 4, seed=3, max_onset=0.5)
-    assert checked >= 3, (checked, skipped)
+    assert checked + skipped == 4
+
+
+def test_loop_c4_as_stated(env):
+    """BASELINE config C4 as stated: mixed-instrument windows (piano / strings / guitar groups 0-2, 2-4 notes),
+    instrument + pitch heads, THREE subtractive iterations, N = 2048 at the full 516 frames -- a few windows of one
+    rank's 1024-window shard, every one compared with the oracle loop."""
+    p = env['hp'].Hyperparams(N=2048)
+    ev, checked, skipped, lp, orc, _ = _run_case(env, p, ('instrument', 'pitch'), 3, 6, seed=4, groups=(0, 1, 2),
+                                                 notes=(2, 4), max_onset=0.5)
+    assert checked + skipped == 6 and checked >= 5
+    assert np.all(ev[..., 3] >= 0) and np.all(ev[..., 4] == -1)            # instrument decided, no velocity head
 
 
 def test_loop_properties_full_size(env):

@@ -43,44 +43,52 @@ def _inputs(shape, B, seed):
     return (rng.random((B,) + tuple(shape)) ** 2).astype(np.float32)
 
 
-def _check_head(env, head, cfg, B, seed, near_tie=0.02, modes=(0, 1, 2), name=None, xs=None):
-    """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16) against the oracle."""
+def _check_head(env, head, cfg, B, seed, modes=(0, 1, 2), name=None, xs=None):
+    """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16) against the oracle (computed once)."""
+    if xs is None:
+        xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
+    xo = [x[..., None] for x in xs]
+    fw = env['orc'].forward
+    refs = dict(lg32=fw(head.weights, cfg, xo, np.float32, return_logits=True),
+                y32=fw(head.weights, cfg, xo, np.float32),
+                lg64=fw(head.weights, cfg, xo, np.float64, return_logits=True),
+                y64=fw(head.weights, cfg, xo, np.float64))
     out = None
     for mode in modes:
         head.set_mode(mode)
-        out = _check_head_mode(env, head, cfg, B, seed, near_tie, name or type(head).__name__, mode, xs)
+        out = _check_head_mode(env, head, cfg, xs, refs, name or type(head).__name__, mode)
     head.set_mode(0)
     return out
 
 
-def _check_head_mode(env, head, cfg, B, seed, near_tie, name, mode, xs=None):
-    if xs is None:
-        xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
+def _check_head_mode(env, head, cfg, xs, refs, name, mode):
     dev = [env['torch'].from_numpy(x).cuda() for x in xs]
     y, lg = head.predict_device(dev, return_logits=True)
     y, lg = y.cpu().numpy(), lg.cpu().numpy()
-    ref_lg = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float32,
-                                return_logits=True)
-    ref = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float32)
-    ref64 = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float64)
+    ref_lg, ref, ref_lg64, ref64 = refs['lg32'], refs['y32'], refs['lg64'], refs['y64']
     scale = max(np.abs(ref_lg).max(), 1.0)
     assert np.abs(lg - ref_lg).max() / scale < REL, np.abs(lg - ref_lg).max()
     assert np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30) < REL
-    # the GPU result is as close to the float64 truth as the float32 CPU result is: measured on the logits
-    # (the quantity every arithmetic mode produces), recorded per head and mode (gpurun_out/
-    # rdcnn_error_vs_f64.json -> profiles/r02/: measured e_gpu / e_cpu 0.1 .. 3.5 in the split modes; the
-    # f32-MFMA mode, a k-ordered fmaf chain over K = 2048, reaches 11 on one timing window where OpenBLAS' blocked
-    # sums are luckier), and bounded at four times the CPU's own distance plus 1e-5 of the logit scale -- a
-    # tenth of the 1e-4 parity tolerance (both distances are maxima over a handful of values: noisy statistics)
-    ref_lg64 = env['orc'].forward(head.weights, cfg, [x[..., None] for x in xs], np.float64, return_logits=True)
+    # The GPU result is as close to the float64 truth as the float32 CPU result is.  Measured on the logits (the
+    # quantity every arithmetic mode produces), recorded per head and mode (gpurun_out/rdcnn_error_vs_f64.json ->
+    # profiles/r03/).  One bar for ALL THREE modes: 2.5 x the CPU's own distance plus two ulps of the logit scale
+    # (round 2 had loosened this to 4 x + 1e-5 scale because the f32-MFMA mode summed K = 2048 products in ONE chain
+    # and sat 11 x farther out than numpy on the timing head; that kernel now sums per (tap, chunk) block, like
+    # OpenBLAS' K-blocking, and is held to the same bar).
     e_gpu = float(np.abs(lg - ref_lg64).max())
     e_cpu = float(np.abs(ref_lg - ref_lg64).max())
-    RATIOS.append(dict(head=name, mode=mode, e_gpu=e_gpu, e_cpu=e_cpu, logit_scale=float(scale)))
-    assert e_gpu <= 4 * e_cpu + 1e-5 * scale, (name, mode, e_gpu, e_cpu)
-    # predicted integer indices: bit-exact away from rounding ties (SURVEY 7 hard part 4)
+    RATIOS.append(dict(head=name, mode=mode, e_gpu=e_gpu, e_cpu=e_cpu, logit_scale=float(scale), windows=len(xs[0])))
+    e_bar = 2.5 * e_cpu + 2.4e-7 * scale
+    assert e_gpu <= e_bar, (name, mode, e_gpu, e_cpu)
+    # predicted integer indices: bit-exact unless the float64 value sits within the arithmetic's own reach of a
+    # rounding boundary -- e_bar mapped through the output activation (slope <= range / 4), doubled (both
+    # roundings move) and with a 2x margin: range x e_bar, ~2e-3 frames on the timing head (round 2: a flat 0.02)
     if cfg['output_classes'] == 1:
+        rng_ = float(cfg['output_range'][1] - cfg['output_range'][0]) if cfg.get('output_range') else 1.0
+        near_tie = rng_ * e_bar
         frac = np.abs(ref64 - np.floor(ref64) - 0.5)
         safe = frac[:, 0] > near_tie
+        assert np.abs(y - ref64).max() <= near_tie
         assert np.array_equal(np.rint(y)[safe], np.rint(ref)[safe])
         assert np.array_equal(np.rint(y)[safe], np.rint(ref64)[safe])
     else:
@@ -96,21 +104,21 @@ def test_velocity_head(env):
     h = env['heads'].VelocityClassifier(p)
     cfg = env['orc'].head_config(p, 'velocity')
     assert cfg['convolutional_layer_count'] == 11
-    _check_head(env, h, cfg, 5, 1, name='velocity')
+    _check_head(env, h, cfg, 8, 1, name='velocity')
 
 
 def test_pitch_head(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].pitch_classifier(p)
     cfg = env['orc'].head_config(p, 'pitch')
-    y = _check_head(env, h, cfg, 3, 2, name='pitch')
-    assert y.shape == (3, 1) and np.all((y >= 21) & (y <= 108))
+    y = _check_head(env, h, cfg, 6, 2, name='pitch')
+    assert y.shape == (6, 1) and np.all((y >= 21) & (y <= 108))
 
 
 def test_instrument_head_and_dual(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].InstrumentClassifier(p, 'instrument')
-    _check_head(env, h, env['orc'].head_config(p, 'instrument'), 2, 3, name='instrument')
+    _check_head(env, h, env['orc'].head_config(p, 'instrument'), 3, 3, name='instrument')
     hd = env['heads'].InstrumentClassifier(p, 'instrument_dual')
     _check_head(env, hd, env['orc'].head_config(p, 'instrument_dual'), 2, 4, name='instrument_dual')
     with pytest.raises(ValueError):
@@ -123,17 +131,17 @@ def test_timing_head_n4096(env):
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
     assert cfg['input_shapes'][0] == (20, 258, 1)
-    _check_head(env, h, cfg, 2, 5, name='timing N=4096')
+    _check_head(env, h, cfg, 6, 5, name='timing N=4096')
 
 
 def test_timing_head_n2048_batch_independent(env):
-    """Metric configuration (20 x 516).  One window vs the oracle, then the
-    size-independent property at a larger batch: a window's output does not
+    """Metric configuration (20 x 516: the head that is 97 % of the flops).  EIGHT stand-alone windows vs the
+    oracle in every arithmetic, then the size-independent property at a larger batch: a window's output does not
     depend on its position in the batch / workgroup window-group."""
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
-    _check_head(env, h, cfg, 1, 6, name='timing N=2048')
+    _check_head(env, h, cfg, 8, 6, name='timing N=2048')
     torch = env['torch']
     x = torch.from_numpy(_inputs((20, 516), 13, 7)).cuda()
     y = h.predict_device([x]).cpu().numpy()
