@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0 with the driver contract plus
   value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
                           (TranscriptionLoop.run_stream), steady state
   prepare_ms              the untimed per-batch set-up (STFT + song-level CQT normalisers)
+  value_prepare_inclusive the same step with that set-up inside the timed region (a fresh batch every step)
 """
 import argparse
 import json
@@ -58,7 +59,6 @@ WORKLOADS = {
                name='C5 shard: 2048 mixed-instrument windows per GPU, all heads, 5 iterations'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SUSTAINED_F16_TF = 1620.0     # measured: scripts/probes/mfma_peak.hip, random operands, 2-4 waves per SIMD
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense FP32 matrix peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense BF16 matrix peak
 
@@ -97,16 +97,13 @@ _ORC = None
 _DATA = None
 
 
-def _cpu_pool_init(wl_name, n_fft, path):
-    global _ORC, _DATA
+def _cpu_pool_init_shared():
     from threadpoolctl import threadpool_limits
     threadpool_limits(limits=1)
-    _ORC = _cpu_worker_setup(wl_name, n_fft)
-    _DATA = np.load(path)
 
 
 def _cpu_pool_task(i):
-    refs = {k[4:]: _DATA[k][i] for k in _DATA.files if k.startswith('ref_')}
+    refs = {k[4:]: _DATA[k][i] for k in _DATA if k.startswith('ref_')}
     t0 = time.perf_counter()
     _ORC.run_window(_DATA['wave'][i], refs, i)
     return time.perf_counter() - t0
@@ -141,20 +138,30 @@ def cpu_baseline_main(wl_name, n_fft, path, budget_s):
     out['single'] = dict(value=done / t_total, unit='windows/s', cores=1, kind='port',
                          sample='%d window(s) of the same workload, numpy oracle (oracle/loop.py), 1 process x 1 thread, '
                                 '%.1f s of CPU work' % (done, t_total))
-    # the GPU box grants this job a share of its cores (16 per GPU); more workers than that only queue
-    workers = max(1, min(avail, int(os.environ.get('AMT_CPU_WORKERS', '16'))))
+    # the GPU box grants this job a share of its cores (16 per GPU); more workers than that only queue.  Leg 2 uses
+    # that share, leg 3 every core the affinity mask shows (Pool(os.cpu_count())), each bounded in time.
+    # The oracle object is built ONCE here and inherited by the forked workers (copy-on-write: no per-worker copy of
+    # the weights and the guess bank).
+    global _ORC, _DATA
+    _ORC, _DATA = orc, {k: np.asarray(data[k]) for k in data.files}      # arrays, not the lazy NpzFile (its file handle must not be shared by forks)
     per_win = t_total / done
-    tasks = int(min(n, max(workers, workers * max(1, int(budget_s / 2 / max(per_win, 1e-3))))))
     ctx = mp.get_context('fork')
-    with ctx.Pool(workers, initializer=_cpu_pool_init, initargs=(wl_name, n_fft, path)) as pool:
-        pool.map(_cpu_pool_task, range(min(workers, n)))               # warm every worker
-        t0 = time.perf_counter()
-        pool.map(_cpu_pool_task, [i % n for i in range(tasks)], chunksize=1)
-        wall = time.perf_counter() - t0
-    out['pool'] = dict(value=tasks / wall, unit='windows/s', cores=workers, kind='port',
-                       sample='%d window task(s) of the same workload over multiprocessing.Pool(%d), one window per task, '
-                              'one BLAS thread per worker (training.py:623-630 worker model), %.1f s wall; host has %d '
-                              'logical cores, %d usable by this process' % (tasks, workers, wall, os.cpu_count() or 0, avail))
+
+    def pool_leg(workers, budget):
+        tasks = int(min(4 * n, max(workers, workers * max(1, int(budget / max(per_win, 1e-3))))))
+        with ctx.Pool(workers, initializer=_cpu_pool_init_shared) as pool:
+            pool.map(_cpu_pool_task, [i % n for i in range(workers)], chunksize=1)       # warm every worker
+            t0 = time.perf_counter()
+            pool.map(_cpu_pool_task, [i % n for i in range(tasks)], chunksize=1)
+            wall = time.perf_counter() - t0
+        return dict(value=tasks / wall, unit='windows/s', cores=workers, kind='port',
+                    sample='%d window task(s) of the same workload over multiprocessing.Pool(%d), one window per task, '
+                           'one BLAS thread per worker (training.py:623-630 worker model), %.1f s wall; host has %d '
+                           'logical cores, %d in this process\'s affinity mask' % (tasks, workers, wall, os.cpu_count() or 0, avail))
+    share = max(1, min(avail, int(os.environ.get('AMT_CPU_WORKERS', '16'))))
+    out['pool'] = pool_leg(share, budget_s / 2)
+    if avail > share:
+        out['pool_all_cores'] = pool_leg(avail, budget_s / 3)
     print('CPU_BASELINE ' + json.dumps(out), flush=True)
 
 
@@ -172,9 +179,11 @@ def cpu_baseline(p, wl_name, wave_cpu, refs_cpu, budget_s):
     for line in r.stdout.splitlines():
         if line.startswith('CPU_BASELINE '):
             legs = json.loads(line[len('CPU_BASELINE '):])
-            best = legs['pool']
-            best = dict(best)
+            # headline = the better of the two Pool legs (its `cores` says which); all three legs are reported
+            best = dict(max([legs[k] for k in ('pool', 'pool_all_cores') if k in legs], key=lambda l: l['value']))
             best['single_thread'] = legs['single']
+            best['pool_gpu_share'] = legs['pool']
+            best['pool_all_cores'] = legs.get('pool_all_cores')
             return best
     raise RuntimeError('cpu baseline worker failed: ' + r.stderr[-2000:])
 
@@ -300,28 +309,46 @@ def main():
     pmc = {}
     if os.path.exists(tf):
         try:
+            # per-launch HBM bytes of the step's OWN launch of each kernel (selected by grid size,
+            # scripts/make_pmc_traffic.py), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
             pmc = json.load(open(tf))
             t = pmc.get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
-            if t:
-                traffic = int(t['hbm_bytes_per_window_per_launch'] * min(B, 1024))     # windows per launch (RD_CHUNK)
+            if t and t.get('windows_per_launch'):
+                traffic = int(t['hbm_bytes_per_launch'] * min(B, 1024) / t['windows_per_launch'])
         except Exception:
             traffic = None
+    # Nothing in this object is a literal: `achieved` comes from HIP events of this run, the sustained-rate
+    # denominator from the probe kernel run in this process right here (amt_probe_mfma_f16: back-to-back
+    # v_mfma_f32_16x16x32_f16 on random non-zero register operands, two waves per SIMD, ~60 ms launches, best of 3),
+    # and what only a separate rocprofv3 --pmc pass can give (HBM traffic, matrix-pipe busy share, held clock) is
+    # copied verbatim from profiles/pmc_derived.json under `from_profiles`, with the files and the commit it was
+    # collected at (scripts/collect_profiles.sh writes it; absent file -> null).
+    sustained = {}
+    if split and conv_mode == 2 and not args.no_extras:
+        import ctypes as C
+        from amt_saga import _lib as alib
+        tf_, ms_ = C.c_double(0.0), C.c_double(0.0)
+        alib.check(alib.load().amt_probe_mfma_f16(2, 200000, 1, 3, C.byref(tf_), C.byref(ms_), None))
+        sustained = {'sustained_f16_mfma_tflops_measured': round(tf_.value, 1),
+                     'sustained_probe': 'amt_probe_mfma_f16(2 waves/SIMD, random operands), %.0f ms launch, this run' % ms_.value,
+                     'executed_vs_sustained': round(achieved_tf * nmf / tf_.value, 3)}
+    from_profiles = None
+    pd = os.path.join(ROOT, 'profiles', 'pmc_derived.json')
+    if os.path.exists(pd):
+        try:
+            from_profiles = json.load(open(pd))
+        except Exception:
+            from_profiles = None
     roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=peak_tf, unit='TFLOP/s',
                     frac=round(achieved_tf / peak_tf, 4), traffic=traffic, kernel=kname,
                     peak_note=('dense bf16/f16 MFMA peak 2500 / %d MFMAs per f32-equivalent product block' % nmf
                                if split else 'dense f32 MFMA peak'),
                     executed_mfma_tflops=round(achieved_tf * (nmf if split else 1), 1),
-                    # scripts/probes/mfma_peak.hip on this chip (profiles/r02/mfma_sustained_probe.txt): back-to-back
-                    # v_mfma_f32_16x16x32_f16 on register operands, nothing else running, sustains 1620 TFLOP/s on
-                    # random non-zero data (2090 on zeros): the power limit, not the schedule, sets the f16 ceiling
-                    **({'sustained_f16_mfma_tflops_measured': SUSTAINED_F16_TF,
-                        'executed_vs_sustained': round(achieved_tf * nmf / SUSTAINED_F16_TF, 3),
-                        # separate rocprofv3 --pmc passes over this kernel (profiles/r02/mfma_util_f16x3.txt): the chip
-                        # is at its power limit while it runs -- the clock falls as the matrix pipe fills
-                        'mfma_pipe_busy_pmc': 0.663, 'held_clock_ghz_pmc': 1.72} if split and conv_mode == 2 else {}),
+                    **sustained,
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
-                    conv_ms_per_step=round(conv_ms_total / args.steps, 2))
+                    conv_ms_per_step=round(conv_ms_total / args.steps, 2),
+                    from_profiles=from_profiles)
     # ---- the north star's HBM pair: only the bytes the step consumes ------------------------
     F, T, ldf = p.N // 2 + 1, p.timing_frames, (p.N // 2 + 1 + 3) & ~3
     stft_ms = sum(e0.elapsed_time(e1) for tag, e0, e1, _ in ev_pairs if tag == 'stft')
@@ -336,8 +363,9 @@ def main():
     stft_traffic = None
     try:
         key = 'stft' if with_phase else 'stft_mag_only'
-        stft_traffic = int((pmc[key]['hbm_bytes_per_window_per_launch'] +
-                            (pmc['subtract']['hbm_bytes_per_window_per_launch'] if n_sub else 0)) * B)
+        stft_traffic = int(pmc[key]['hbm_bytes_per_launch'] * B / pmc[key]['windows_per_launch'] +
+                           (pmc['subtract']['hbm_bytes_per_launch'] * B / pmc['subtract']['windows_per_launch']
+                            if n_sub else 0))
     except Exception:
         stft_traffic = None
     roofline_stft = dict(bound='hbm', achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
@@ -363,6 +391,16 @@ def main():
             for n in loop.nets.values():
                 n.set_mode(conv_mode)
             step()
+        # (1a) the step INCLUDING the per-batch song-level normalisers (prepare(): whole-CQT maxima of every window,
+        # each window standing for its song -- training.py:271-282 computes them once per song): what a stream of
+        # fresh batches costs when nothing about a batch is known in advance
+        def step_fresh():
+            ev, b = loop.run(wave, window0=window0, refs=None)
+            return adist.gather_events(ev.reshape(-1, 7), n_total=B * world * wl['iters']), b
+        step_fresh()
+        kp = max(1, min(args.steps, 5))
+        dtp, _ = timed_steps(kp, step_fresh)
+        extras['value_prepare_inclusive'] = round(B * world * kp / dtp, 2)
         # (1b) timing_end on a second stream under timing_start (TranscriptionLoop.timing_streams = 2, opt-in: it fills
         # the tails of the small-image launches, but two kernels then share the chip and a kernel's own duration --
         # the roofline's denominator -- is no longer defined; so it is an extra leg, not the default)

@@ -327,6 +327,15 @@ int amt_trainer_step(amt_trainer *trainer, const float *const *x, const float *y
 int amt_trainer_get_weights(amt_trainer *trainer, float *weights_host, size_t n_floats);
 int amt_trainer_get_grads(amt_trainer *trainer, float *grads_host, size_t n_floats);
 
+/* ------------------------------------------------------------------------ *
+ * Measurement probe (no reference counterpart; bench.py's roofline object).  Sustained rate of back-to-back
+ * v_mfma_f32_16x16x32_f16 on register operands with `waves_per_simd` waves per SIMD on every CU, `iters` x 8
+ * MFMAs per wave and launch, best of `launches`; random_operands != 0: random non-zero f16 operands (the rate
+ * the power limit allows on live data), 0: zeros (the cycle-limited rate).  Synchronises the stream.
+ * ------------------------------------------------------------------------ */
+int amt_probe_mfma_f16(int waves_per_simd, int iters, int random_operands, int launches,
+                       double *tflops_best, double *ms_best, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

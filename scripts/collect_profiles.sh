@@ -24,6 +24,8 @@ python3 $R/scripts/summarize_pmc.py /tmp/prof_f FETCH_SIZE $OUT/pmc_fetch.csv >>
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -- \
     python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline --no-extras > $OUT/bench_pmc_write.json 2> $OUT/pw.err
 python3 $R/scripts/summarize_pmc.py /tmp/prof_w WRITE_SIZE $OUT/pmc_write.csv >> $OUT/pw.err 2>&1
+python3 $R/scripts/make_pmc_traffic.py $OUT/pmc_fetch.csv $OUT/pmc_write.csv 256 $TAG > $OUT/pmc_traffic.log 2>&1
+cp $R/profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # C5's per-GPU shard: 2048 windows, all heads, 5 iterations (kernel trace only)
 rm -rf /tmp/prof_c5
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -- \

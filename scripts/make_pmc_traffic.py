@@ -1,47 +1,64 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the per-kernel FETCH_SIZE / WRITE_SIZE sums of
-scripts/collect_profiles.sh (separate --pmc passes of `bench.py --windows 256 --steps 1`).
+"""profiles/pmc_traffic.json from the per-(kernel, grid) FETCH_SIZE / WRITE_SIZE rows of scripts/summarize_pmc.py
+(separate --pmc passes of `bench.py --windows W --steps 1`, scripts/collect_profiles.sh).
 
-    python scripts/make_pmc_traffic.py <pmc_fetch.csv> <pmc_write.csv> [windows]
+    python scripts/make_pmc_traffic.py <pmc_fetch.csv> <pmc_write.csv> <windows W> [tag]
 
-Per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
-of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is.  The
-dominant dispatch class of each kernel family (largest per-dispatch traffic) is reported."""
-import csv, json, os, sys
+Per MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the
+bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is.
 
-fetch, write = sys.argv[1], sys.argv[2]
-windows = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false>',
-            'conv_bf16x6': 'conv_bf16x6_kernel<4, 16, 32, 32, false>',
+For every kernel family the STEP'S OWN launch class is selected by grid size -- the largest grid of that kernel in the
+run: the step's STFT covers all W windows (the guess bank's STFT and a small last conv layer have smaller grids), the
+20 x 516 convolution launches of a chunk all share one grid -- and the figure is that class's sum / its dispatches.
+(Round 2 divided a kernel's total by all its dispatches, mixing unequal launches; its file also kept stale families:
+the output is rewritten from scratch every time.)"""
+import csv, json, os, subprocess, sys
+
+fetch, write, windows = sys.argv[1], sys.argv[2], int(sys.argv[3])
+tag = sys.argv[4] if len(sys.argv) > 4 else ''
+FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false',
             'conv_mfma': 'conv_mfma_kernel<4, 16, 32, 32',
-            'stft': 'stft_mag_kernel<2048, true>', 'stft_mag_only': 'stft_mag_kernel<2048, false>',
-            'subtract': 'subtract_kernel'}
+            'stft': 'stft_mag_kernel<2048, true', 'stft_mag_only': 'stft_mag_kernel<2048, false',
+            'subtract': 'subtract_kernel', 'compress_bands': 'compress_bands_kernel',
+            'cqt_window_max': 'cqt_blocks_kernel<false'}
 
 
 def load(path):
     out = {}
     for r in csv.DictReader(open(path)):
         cols = list(r.keys())
-        out[r['kernel']] = (int(r['dispatches']), float(r[cols[3]]))
+        out[(r['kernel'], int(r['grid_size']))] = (int(r['dispatches']), float(r[cols[3]]))
     return out
+
+
+def pick(table, pat):
+    """The (kernel, grid) class with the largest grid among the kernels matching pat."""
+    keys = [k for k in table if pat in k[0]]
+    return max(keys, key=lambda k: k[1]) if keys else None
 
 
 f, w = load(fetch), load(write)
 res = {}
 for fam, pat in FAMILIES.items():
-    kf = [k for k in f if pat in k]
-    kw = [k for k in w if pat in k]
-    if not kf or not kw:
+    kf, kw = pick(f, pat), pick(w, pat)
+    if not kf or not kw or kf[1] != kw[1]:
         continue
-    fk, wk = f[kf[0]][1], w[kw[0]][1]
-    res[fam] = {
-        'fetch_size_kb_per_dispatch': round(fk, 1), 'write_size_kb_per_dispatch': round(wk, 1),
-        'windows_per_dispatch': windows,
-        'hbm_bytes_per_window_per_launch': round((2 * fk + wk) * 1024 / windows, 1),
-        'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); '
-                'WRITE_SIZE as is; separate --pmc passes, bench.py --windows %d --steps 1' % windows}
+    (nf, sf), (nw, sw) = f[kf], w[kw]
+    fk, wk = sf / nf, sw / nw
+    res[fam] = {'kernel': kf[0].split('(')[0], 'grid_size': kf[1], 'dispatches_in_class': nf,
+                'fetch_size_kb_per_launch': round(fk, 1), 'write_size_kb_per_launch': round(wk, 1),
+                'windows_per_launch': windows,
+                'hbm_bytes_per_launch': round((2 * fk + wk) * 1024, 1),
+                'hbm_bytes_per_window': round((2 * fk + wk) * 1024 / windows, 1)}
+try:
+    commit = os.environ.get('AMT_HEAD_COMMIT') or subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=os.path.dirname(os.path.abspath(__file__)),
+                                     text=True).strip()
+except Exception:
+    commit = None
+res['_provenance'] = {'source': [os.path.basename(fetch), os.path.basename(write)], 'profiles_dir': tag, 'commit': commit,
+                      'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE '
+                              'as is; separate --pmc passes of bench.py --windows %d --steps 1; the step\'s own launch class '
+                              '(largest grid) of each kernel' % windows}
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
-old = json.load(open(dst)) if os.path.exists(dst) else {}
-old.update(res)
-json.dump(old, open(dst, 'w'), indent=1)
+json.dump(res, open(dst, 'w'), indent=1)
 print(json.dumps(res, indent=1))

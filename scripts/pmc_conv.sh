@@ -35,5 +35,21 @@ for k in acc:
         cyc = a['GRBM_GUI_ACTIVE'] / 8.0
         print('   -> MFMA pipe busy %.1f %% of SIMD cycles' % (100.0 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc)))
         if wall.get(k): print('   -> effective clock %.2f GHz (kernel-trace wall %.3f ms over %d dispatches)' % (cyc / wall[k] / 1e9, wall[k] * 1e3, nk[k]))
+# machine-readable copy for bench.py's roofline.from_profiles (the dominant kernel = most MFMA-busy cycles)
+import json, os, subprocess
+dom = max((k for k in acc if acc[k].get('GRBM_GUI_ACTIVE') and acc[k].get('SQ_VALU_MFMA_BUSY_CYCLES')),
+          key=lambda k: acc[k]['SQ_VALU_MFMA_BUSY_CYCLES'], default=None)
+if dom:
+    a = acc[dom]; cyc = a['GRBM_GUI_ACTIVE'] / 8.0
+    R = os.environ.get('GRAFT_REPO_ROOT', os.getcwd())
+    commit = os.environ.get('AMT_HEAD_COMMIT')          # .git does not travel to the GPU box: the caller passes it
+    d = dict(kernel=dom, mfma_pipe_busy=round(a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc), 4),
+             held_clock_ghz=round(cyc / wall[dom] / 1e9, 3) if wall.get(dom) else None,
+             lds_wait_share=round(a.get('SQ_WAIT_INST_LDS', 0) / a['SQ_WAVE_CYCLES'], 4) if a.get('SQ_WAVE_CYCLES') else None,
+             dispatches=n[dom], commit=commit,
+             source='scripts/pmc_conv.sh: separate rocprofv3 --pmc passes (8 SQ counters; GRBM_GUI_ACTIVE) + a kernel-trace pass '
+                    'of scripts/conv_microbench.py timing %s mode %s' % (os.environ.get('PMC_B', '128'), os.environ.get('PMC_MODES', '0,1')),
+             formulas='busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / kernel-trace wall')
+    json.dump(d, open(os.path.join(R, 'gpurun_out', 'pmc_conv', 'pmc_derived.json'), 'w'), indent=1)
 PY
 cat $OUT/micro.log; cat $OUT/sq_summary.txt
