@@ -75,6 +75,9 @@ PROTOTYPES = {
     'amt_cqt_coef': (C.c_int, [vp, vp, C.c_int, vp, vp]),
     'amt_cqt_window_max_workspace': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'amt_cqt_window_max': (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_size_t, vp]),
+    'amt_cqt_mfma_table_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'amt_cqt_mfma_table': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    'amt_cqt_window_max_mfma': (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
     'amt_round_clamp': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'amt_argmax_rows': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     'amt_resize_table': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

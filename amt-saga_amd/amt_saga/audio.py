@@ -277,14 +277,40 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     return out
 
 
-def cqt_window_max(wave, table, hop):
+_MFMA_TABLES = {}          # (phase_inc ptr, length ptr, n_bins, hop) -> (device table, the tensors it was built from)
+
+
+def cqt_window_max(wave, table, hop, form='auto'):
     """max over every bin of `table` and every STFT-grid frame 0 .. L // hop of the signals' CQT: the song-level
     normalisers np.max(slice_C(0, duration, n_frames, ...)) of training.py:271-282.  wave [B, L] f32 device --
-    windows, or a whole song as one row; table from cqt_table(..., device).  Returns [B]."""
+    windows, or a whole song as one row; table from cqt_table(..., device).  Returns [B].
+    form: 'auto' = the MFMA form (one GEMM per window against a phasor table, amt_cqt_window_max_mfma) where its
+    geometry fits -- batches of windows of at most 544 hop-blocks -- else the O(L)-per-bin VALU form
+    (amt_cqt_window_max: any length, a whole song included); 'valu' / 'mfma' force one."""
     lib = _lib.load()
     B, L = wave.shape
     n_bins = int(table[0].shape[0])
     out = empty((B,))
+    if form not in ('auto', 'valu', 'mfma'):
+        raise ValueError('Requested attribute does not exist')
+    if form != 'valu':
+        key = (table[0].data_ptr(), table[1].data_ptr(), n_bins, int(hop))
+        ent = _MFMA_TABLES.get(key)
+        nbytes = int(lib.amt_cqt_mfma_table_bytes(int(hop), n_bins))
+        if ent is None and nbytes:
+            tab = empty(((nbytes + 3) // 4,), torch.int32)
+            _lib.check(lib.amt_cqt_mfma_table(ptr(table[0]), ptr(table[1]), n_bins, int(hop), ptr(tab), stream_ptr()))
+            ent = _MFMA_TABLES[key] = (tab, table[0], table[1])       # keeps the source tensors (and their addresses) alive
+        if ent is not None:
+            scratch = empty((B,))
+            st = lib.amt_cqt_window_max_mfma(ptr(wave), B, L, _stride0(wave), int(hop), ptr(table[0]), ptr(table[1]),
+                                             ptr(ent[0]), n_bins, ptr(out), ptr(scratch), stream_ptr())
+            if st == _lib.AMT_OK:
+                return out
+            if st != _lib.AMT_E_UNSUPPORTED or form == 'mfma':
+                _lib.check(st)
+        elif form == 'mfma':
+            _lib.check(_lib.AMT_E_UNSUPPORTED)
     need = int(lib.amt_cqt_window_max_workspace(L, int(hop), n_bins, B))
     ws = empty(((need + 7) // 8,), torch.float64) if need else None
     _lib.check(lib.amt_cqt_window_max(ptr(wave), B, L, _stride0(wave), int(hop), ptr(table[0]), ptr(table[1]),

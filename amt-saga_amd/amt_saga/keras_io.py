@@ -86,8 +86,21 @@ def load_keras_weights(path, layout):
     for ln, arrays in by_layer.items():
         if arrays:
             pools.setdefault(_layer_class(ln), []).append((_counter(ln), ln))
-    for v in pools.values():
+    # Keras' name counters are per process, not per model: a model built after another one in the same process
+    # starts at conv2d_34 / batch_normalization_53 / dense_3 (and tf.keras 2.x names the first instance without a
+    # suffix).  Only the ORDER of the counters inside a class matters, so offsets and gaps are accepted; what cannot
+    # be ordered is rejected: two weighted layers of one class with the same counter, or a weighted layer class the
+    # builder of RDCNN.py:176-233 never creates.
+    known = {'conv2d', 'batch_normalization', 'dense'}
+    for cls, v in pools.items():
+        if cls not in known:
+            raise ValueError('Invalid Input shape. Expected: layers of {} . Got: weighted layer(s) {}'.format(
+                sorted(known), ', '.join(ln for _, ln in v[:4])))
         v.sort()
+        dup = [b for a, b in zip(v, v[1:]) if a[0] == b[0]]
+        if dup:
+            raise ValueError('Invalid Input shape. Expected: distinct name counters per layer class . Got: {} twice '
+                             '(ambiguous creation order)'.format(dup[0][1]))
     shapes = dict(layout)
     w = {}
 
@@ -120,7 +133,12 @@ def load_keras_weights(path, layout):
 def keras_layers(cfg):
     """[(layer name, canonical prefix or None)] in ``model.layers`` order for the graph RDCNN.py:176-233 builds:
     names ``<class>_<n>`` from per-class creation counters (Keras' automatic naming), order by graph depth
-    (longest path to the output, as keras.engine.network sorts its layers), ties by creation."""
+    (longest path to the output), and -- as keras.engine.network._map_graph_network does -- layers of EQUAL depth by
+    their traversal index: a pre-order depth-first walk from the output over each layer's inbound layers in call
+    order.  ``Add()([intermediate, layer_to])`` (RDCNN.py:316,335) lists the shortcut branch first, so at a projected
+    shortcut the 1x1 Conv2D precedes the main branch's Conv2D of equal depth and tower 0 precedes tower 1
+    (``Concatenate()(layers)``).  Round 2 broke ties by creation order, which swaps those two convolutions.
+    Keras itself is not available here: this order is restated from its source, not pinned by a Keras-written file."""
     counters, nodes = {}, []
 
     def new(cls, prefix, inputs):
@@ -167,7 +185,15 @@ def keras_layers(cfg):
     for idx in range(len(nodes) - 1, -1, -1):
         for j in nodes[idx][2]:
             depth[j] = max(depth[j], depth[idx] + 1)
-    order = sorted(range(len(nodes)), key=lambda k: (-depth[k], k))
+    # traversal index: pre-order DFS from the output, inbound layers in call order (explicit stack: no recursion limit)
+    index, stack = {}, [len(nodes) - 1]
+    while stack:
+        k = stack.pop()
+        if k in index:
+            continue
+        index[k] = len(index)
+        stack.extend(reversed(nodes[k][2]))
+    order = sorted(range(len(nodes)), key=lambda k: (-depth[k], index[k]))
     return [(nodes[k][0], nodes[k][1]) for k in order]
 
 

@@ -127,7 +127,7 @@ class res_net:
         self.metrics_test = []
         self._net = None
         self._ws = None
-        self.weights = None
+        self._weights = None
         self.mode = DEFAULT_MODE
         self.layout = self._walk()
         if weights_load_checkpoint_filename is not None:
@@ -250,7 +250,7 @@ class res_net:
 
     def set_weights(self, w):
         """Upload a weight dict (see module docstring) to the device."""
-        self.weights = w
+        self._weights = w
         self._blob = self.pack_weights(w)
         self._release()
 
@@ -381,22 +381,44 @@ class res_net:
     def _scale_activation_to_output(self, x):               # RDCNN.py:308-310
         return ((x - self.out_func_min) / self.out_func_factor) * self.out_val_factor + self.out_val_min
 
+    @property
+    def weights(self):
+        """Canonical weight dict.  After train() the live weights are on the device; reading this pulls them back
+        first, so the dict is never stale (bench / smoke / save read it directly)."""
+        self._sync_from_trainer()
+        return self._weights
+
+    @weights.setter
+    def weights(self, w):
+        self._weights = w
+
+    # Keras' Adagrad defaults changed TOGETHER between versions, and the reference (``keras.optimizers.Adagrad()``,
+    # RDCNN.py:246-253) pins none: Keras 2.2 / tf.keras 1.13: lr 0.01, accumulator 0, epsilon K.epsilon() = 1e-7;
+    # tf.keras >= 1.14 (optimizer_v2): lr 0.001, initial accumulator 0.1, epsilon 1e-7.  ``keras_optimizer_version``
+    # selects one consistent triple (default: the reference's era, 'keras-2.2'); the individual attributes
+    # ``learning_rate`` / ``adagrad_epsilon`` / ``adagrad_initial_accumulator`` still override it.
+    ADAGRAD_DEFAULTS = {'keras-2.2': (0.01, 1e-7, 0.0), 'tf.keras-1.14': (0.001, 1e-7, 0.1)}
+    keras_optimizer_version = 'keras-2.2'
+
     # ---- training side (RDCNN.py:503-589): amt_trainer_step on the device ----------------------------
     def _trainer_handle(self):
         """The device-side trainer, created from the current weights on first use.  From then on it owns
         the live weights; predict() pulls them back before its next forward (``_sync_from_trainer``).
-        Optimiser = Adagrad as RDCNN.py:246-253 compiles it; attributes ``learning_rate`` (0.01),
-        ``adagrad_epsilon`` (1e-7) and ``adagrad_initial_accumulator`` (0.1 = tf.keras >= 1.14; set 0.0 for
-        Keras 2.2 / tf.keras 1.13) may be set before the first train() call."""
+        Optimiser = Adagrad as RDCNN.py:246-253 compiles it; ``keras_optimizer_version`` picks the (lr, epsilon,
+        initial accumulator) triple of one Keras generation (see ADAGRAD_DEFAULTS); ``learning_rate``,
+        ``adagrad_epsilon`` and ``adagrad_initial_accumulator`` override single values; all before the first train()."""
         if getattr(self, '_trainer', None) is None:
             lib = _lib.load()
             require_gpu()
             d = self._desc()
             h = C.c_void_p()
+            if self.keras_optimizer_version not in self.ADAGRAD_DEFAULTS:
+                raise ValueError('Requested attribute does not exist')
+            lr0, eps0, acc0 = self.ADAGRAD_DEFAULTS[self.keras_optimizer_version]
             _lib.check(lib.amt_trainer_create(C.byref(h), C.byref(d), self._blob.ctypes.data_as(C.c_void_p),
-                                              self._blob.size, float(getattr(self, 'learning_rate', 0.0)),
-                                              float(getattr(self, 'adagrad_epsilon', 0.0)),
-                                              float(getattr(self, 'adagrad_initial_accumulator', 0.1))))
+                                              self._blob.size, float(getattr(self, 'learning_rate', lr0)),
+                                              float(getattr(self, 'adagrad_epsilon', eps0)),
+                                              float(getattr(self, 'adagrad_initial_accumulator', acc0))))
             self._trainer, self._tlib, self._trained = h, lib, False
         return self._trainer
 
@@ -409,7 +431,7 @@ class res_net:
                 n = int(np.prod(shape))
                 w[name] = blob[off:off + n].reshape(shape).copy()
                 off += n
-            self.weights, self._blob = w, blob
+            self._weights, self._blob = w, blob
             if self._net is not None:
                 self._lib.amt_rdcnn_destroy(self._net)
             self._net = None
@@ -417,8 +439,9 @@ class res_net:
 
     def gradients(self):
         """Gradients of the last train() call as a weight-shaped dict (zeros for BN moving statistics)."""
+        h = self._trainer_handle()                      # creates the trainer (and self._tlib) if train() has not run yet
         blob = np.empty(self._blob.size, np.float32)
-        _lib.check(self._tlib.amt_trainer_get_grads(self._trainer_handle(), blob.ctypes.data_as(C.c_void_p), blob.size))
+        _lib.check(self._tlib.amt_trainer_get_grads(h, blob.ctypes.data_as(C.c_void_p), blob.size))
         out, off = {}, 0
         for name, shape in self.layout:
             n = int(np.prod(shape))
@@ -445,9 +468,11 @@ class res_net:
         pred = empty((B, K))
         loss = C.c_float(0.0)
         arr = (C.c_void_p * len(dx))(*[t.data_ptr() for t in dx])
-        _lib.check(self._tlib.amt_trainer_step(h, arr, ptr(to_dev(yv.astype(np.float32))), B, int(update),
+        y_dev = to_dev(yv.astype(np.float32))           # kept alive across the (asynchronous) step: no temporary
+        _lib.check(self._tlib.amt_trainer_step(h, arr, ptr(y_dev), B, int(update),
                                                C.byref(loss), ptr(pred), stream_ptr()))
         p = pred.cpu().numpy()
+        del y_dev
         return float(loss.value), (self._scale_activation_to_output(p) if self.output_classes == 1 else p)
 
     def train(self, x, y):

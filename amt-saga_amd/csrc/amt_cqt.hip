@@ -301,6 +301,328 @@ __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict
     if (lane == 0) atomicMax(a.out_max + b, __float_as_uint(vmax));   // non-negative floats order as their bits
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA form of the whole-window maximum (amt_cqt_window_max_mfma): the block sums as ONE split-fp16 GEMM per window
+// against a per-bin phasor table, on a BIN-INDEPENDENT block grid, so that the window is streamed once for a whole
+// group of bins instead of once per bin (the VALU form above re-reads the 1 MB window for every bin: 4 B of L2->L1
+// traffic and 3 packed FMAs per sample-bin; 157 ms per 1024 windows on the 1392-bin grid).
+//
+// Uniform blocks j = samples [jH, (j+1)H) whatever the bin.  With z0[m] = x[m] e^{-i phi m},
+// z+-[m] = z0[m] e^{+-i theta (m + N_k/2)} and P(n) = sum_{m<n} z[m], frame t (samples [tH - N_k/2, tH - N_k/2 + N_k))
+// is S_t = P(b_t) - P(a_t), and both ends sit at a FIXED offset inside their uniform block:
+//     a_t = (t - hq) H + cut_s,   b_t = (t + eq) H + cut_e          (hq, eq, cut_s, cut_e depend on the bin only)
+// so   S_t = PF(t + eq) - PF(t - hq) + Ge_{t+eq} - Gs_{t-hq},   PF(j) = sum_{j'<j} F_j'  (f64),
+//     F_j = sum over block j,  Gs_j / Ge_j = sum over its first cut_s / cut_e samples.
+// Per bin that is 18 real columns (F, Gs, Ge  x  z0, z+, z-  x  re, im) of a GEMM whose A operand is the window
+// itself, [blocks][H], identical for every bin:  C[blocks][18 n_bins] = X[blocks][H] x Tab[H][18 n_bins], where
+// Tab holds the phasors RELATIVE to the block start (the masks of Gs / Ge are zeros in the table) and the block's
+// start phase (integer-exact, as above) is applied once per (bin, block) afterwards.
+// Arithmetic: split-fp16 (x 2^s = h + l, both f16: 22 significant bits relative to the window's max |x|; the table
+// likewise), three v_mfma_f32_16x16x32_f16 per product block (h h, h l, l h) into one f32 accumulator -- the dropped
+// l l term and the flushed tiny l are < 2^-22 of max|x| max|tab| per product.
+// Workgroup = (group of CQM_BINS bins, window), 512 threads: wave w owns M-tiles w, w+8, ... (its rows of the A slab
+// live in a wave-private LDS region: no workgroup barrier for A), up to two leftover M-tiles are split over the waves
+// by N-tile; the table slab of a k-step (32 samples) is shared and double-buffered: one barrier per k-step.  The
+// next k-step's samples and table slab are in flight (registers) under the current k-step's MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define CQM_BINS 7                      // bins per workgroup
+#define CQM_NT 8                        // N-tiles of 16 columns: 7 x 18 = 126 of 128 columns used
+#define CQM_MT 4                        // private M-tiles per wave
+#define CQM_RS 2                        // shared (leftover) M-tiles
+#define CQM_TSCALE 8.0f                 // table entries are scaled by 2^3 (|entry| <= 8)
+typedef _Float16 cq_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cq_h4 __attribute__((ext_vector_type(4)));
+typedef float cq_f4 __attribute__((ext_vector_type(4)));
+
+struct CqmArgs {
+    const float *wave; size_t wave_stride;
+    const unsigned int *phase_inc; const int *length;
+    const _Float16 *table;              // [groups][KS][2 planes][128 cols][32]
+    const float *amax;                  // [B] max |x| of each window
+    unsigned int *out_max;              // [B] float bits, zeroed by the caller
+    int L, H, hshift, T, n_bins, nblk, q, r, KS;
+};
+
+// table: column col of group g = bin g * CQM_BINS + col / 18, component col % 18 = set * 6 + kind * 2 + part
+//   set 0: F (all samples), 1: Gs (samples < cut_s), 2: Ge (samples < cut_e);  kind 0: e^{-i phi i}, 1: x e^{+i theta i},
+//   2: x e^{-i theta i};  part 0 / 1: real / imaginary
+__global__ void cqt_mfma_table_kernel(const unsigned int *__restrict__ phase_inc, const int *__restrict__ length, int n_bins,
+                                      int H, int hshift, _Float16 *__restrict__ table, size_t n_total) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_total) return;
+    const int i = (int)(e & 31), col = (int)((e >> 5) & 127);
+    const int KS = H >> 5;
+    const size_t gc = e >> 12;                              // g * KS + c
+    const int c = (int)(gc % KS), g = (int)(gc / KS);
+    const int k = g * CQM_BINS + col / 18, comp = col % 18;
+    float v = 0.f;
+    if (col < CQM_BINS * 18 && k < n_bins) {
+        const int nk = length[k], half = nk >> 1;
+        const int hq = (half + H - 1) >> hshift, cut_s = (hq << hshift) - half;
+        const int rem = nk - half, cut_e = rem - ((rem >> hshift) << hshift);
+        const int ii = 32 * c + i, set = comp / 6, kind = (comp % 6) >> 1, part = comp & 1;
+        const bool on = set == 0 || (set == 1 ? ii < cut_s : ii < cut_e);
+        if (on) {
+            const double ph = (double)phase_inc[k] * 4.656612873077393e-10 * (double)ii;     // phi ii in half-turns
+            const double th = 2.0 / (double)nk * (double)ii;                                // theta ii
+            double sn, cs;
+            sincospi(kind == 0 ? -ph : (kind == 1 ? th - ph : -th - ph), &sn, &cs);
+            v = (float)((part ? sn : cs) * (double)CQM_TSCALE);
+        }
+    }
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const size_t base = gc * (size_t)(2 * 128 * 32) + (size_t)col * 32 + i;
+    table[base] = h;
+    table[base + 128 * 32] = l;
+}
+
+__global__ __launch_bounds__(256) void cqt_amax_kernel(const float *__restrict__ wave, size_t wave_stride, int L,
+                                                        float *__restrict__ amax) {
+    __shared__ float red[16];
+    const float *x = wave + (size_t)blockIdx.x * wave_stride;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) amax[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cqm_smem[];
+    _Float16 *a_priv = (_Float16 *)cqm_smem;                       // [8 waves][2 planes][64 rows][32]          64 KB
+    _Float16 *a_shr = a_priv + 8 * 2 * 64 * 32;                    // [2 buffers][2 planes][32 rows][32]         8 KB
+    _Float16 *b_lds = a_shr + 2 * 2 * 32 * 32;                     // [2 buffers][2 planes][128 cols][32]       32 KB
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int L = a.L, H = a.H, hshift = a.hshift, KS = a.KS, q = a.q, r = a.r, nblk = a.nblk;
+    const float *x = a.wave + (size_t)b * a.wave_stride;
+    // per-window operand scale: max |x| 2^sx in [2^11, 2^12)
+    int sx = 0;
+    {
+        const float am = a.amax[b];
+        int e = 0;
+        if (am > 0.f && am < INFINITY) { (void)frexpf(am, &e); sx = 12 - e; }
+        sx = min(max(sx, -100), 100);
+    }
+    const float xs = ldexpf(1.0f, sx);
+
+    typedef float cqm_f4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto load4 = [&](int row, int col4, int c) -> cq_f4 {
+        const long m = (long)row * H + 32 * c + 4 * col4;
+        if (row < nblk && m + 3 < L) return *(const cqm_f4u *)(x + m);
+        cq_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nblk) {
+            if (m < L) v.x = x[m];
+            if (m + 1 < L) v.y = x[m + 1];
+            if (m + 2 < L) v.z = x[m + 2];
+        }
+        return v;
+    };
+    auto split_store = [&](cq_f4 v, _Float16 *ph, _Float16 *pl) {
+        v *= xs;
+        cq_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        cq_h4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
+                   (_Float16)(v.w - (float)h.w)};
+        *(cq_h4 *)ph = h;
+        *(cq_h4 *)pl = l;
+    };
+    cq_f4 apre[2 * CQM_MT], spre;
+    uint4 bpre[2];
+    const uint4 *tab4 = (const uint4 *)(a.table + (size_t)g * KS * (2 * 128 * 32));
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < CQM_MT; ++i)
+            if (i < q) {
+                const int row0 = 16 * (wid + 8 * i) + (lane >> 3);
+                apre[2 * i] = load4(row0, lane & 7, c);
+                apre[2 * i + 1] = load4(row0 + 8, lane & 7, c);
+            }
+        if (tid < 128 * r) spre = load4(16 * (8 * q + (tid >> 7)) + ((tid & 127) >> 3), tid & 7, c);
+        const uint4 *src = tab4 + (size_t)c * (2 * 128 * 32 * 2 / 16);
+        bpre[0] = src[tid];
+        bpre[1] = src[tid + 512];
+    };
+    auto commit = [&](int c) {                       // registers -> LDS (wave-private A; shared A / B into buffer c & 1)
+        _Float16 *ap = a_priv + (size_t)wid * (2 * 64 * 32);
+#pragma unroll
+        for (int i = 0; i < CQM_MT; ++i)
+            if (i < q) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rl = 16 * i + 8 * u + (lane >> 3);
+                    split_store(apre[2 * i + u], ap + rl * 32 + 4 * (lane & 7), ap + (64 + rl) * 32 + 4 * (lane & 7));
+                }
+            }
+        if (tid < 128 * r) {
+            _Float16 *sp = a_shr + (size_t)(c & 1) * (2 * 32 * 32);
+            const int rl = 16 * (tid >> 7) + ((tid & 127) >> 3);
+            split_store(spre, sp + rl * 32 + 4 * (tid & 7), sp + (32 + rl) * 32 + 4 * (tid & 7));
+        }
+        uint4 *bd = (uint4 *)(b_lds + (size_t)(c & 1) * (2 * 128 * 32));
+        bd[tid] = bpre[0];
+        bd[tid + 512] = bpre[1];
+    };
+
+    cq_f4 acc[CQM_MT][CQM_NT], accs[CQM_RS];
+#pragma unroll
+    for (int i = 0; i < CQM_MT; ++i)
+#pragma unroll
+        for (int n = 0; n < CQM_NT; ++n) acc[i][n] = cq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < CQM_RS; ++s_) accs[s_] = cq_f4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    const int fr = (lane & 15) * 32 + 8 * (lane >> 4);               // fragment offset inside a [16][32] tile (halfs)
+    for (int c = 0; c < KS; ++c) {
+        commit(c);
+        __syncthreads();
+        if (c + 1 < KS) fetch(c + 1);
+        const _Float16 *ap = a_priv + (size_t)wid * (2 * 64 * 32);
+        const _Float16 *sp = a_shr + (size_t)(c & 1) * (2 * 32 * 32);
+        const _Float16 *bp = b_lds + (size_t)(c & 1) * (2 * 128 * 32);
+        cq_h8 ah[CQM_MT], al[CQM_MT];
+#pragma unroll
+        for (int i = 0; i < CQM_MT; ++i)
+            if (i < q) {
+                ah[i] = *(const cq_h8 *)(ap + 16 * i * 32 + fr);
+                al[i] = *(const cq_h8 *)(ap + (64 + 16 * i) * 32 + fr);
+            }
+#pragma unroll
+        for (int n = 0; n < CQM_NT; ++n) {
+            const cq_h8 bh = *(const cq_h8 *)(bp + 16 * n * 32 + fr);
+            const cq_h8 bl = *(const cq_h8 *)(bp + (128 + 16 * n) * 32 + fr);
+#pragma unroll
+            for (int i = 0; i < CQM_MT; ++i)
+                if (i < q) {
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][n], 0, 0, 0);
+                }
+        }
+        // leftover M-tiles: this wave takes N-tile `wid` of each
+        {
+            const cq_h8 bh = *(const cq_h8 *)(bp + 16 * wid * 32 + fr);
+            const cq_h8 bl = *(const cq_h8 *)(bp + (128 + 16 * wid) * 32 + fr);
+#pragma unroll
+            for (int s_ = 0; s_ < CQM_RS; ++s_)
+                if (s_ < r) {
+                    const cq_h8 sh = *(const cq_h8 *)(sp + 16 * s_ * 32 + fr);
+                    const cq_h8 sl = *(const cq_h8 *)(sp + (32 + 16 * s_) * 32 + fr);
+                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bh, accs[s_], 0, 0, 0);
+                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bl, accs[s_], 0, 0, 0);
+                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sl, bh, accs[s_], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();                                 // every wave is done with the operand buffers: reuse them below
+
+    // ---- epilogue, bin by bin: raw block sums -> LDS, start phases, f64 prefix, frames ------------------------------
+    const int nrow = 16 * (8 * q + r);
+    float *R = (float *)cqm_smem;                    // [nrow][18]
+    double *pf = (double *)(cqm_smem + (((size_t)nrow * 18 * 4 + 15) & ~(size_t)15));      // [nblk + 1][6]
+    const float unscale = ldexpf(1.0f, -sx) / CQM_TSCALE;
+    float vmax = 0.f;
+    for (int bb = 0; bb < CQM_BINS; ++bb) {
+        const int k = g * CQM_BINS + bb;
+        if (k >= a.n_bins) break;                    // uniform
+        const int c0 = 18 * bb, nt0 = c0 >> 4;
+#pragma unroll
+        for (int n = 0; n < CQM_NT; ++n) {
+            if (n != nt0 && n != nt0 + 1) continue;  // uniform
+            const int cc = 16 * n + (lane & 15) - c0;
+            if (cc < 0 || cc >= 18) continue;
+#pragma unroll
+            for (int i = 0; i < CQM_MT; ++i)
+                if (i < q) {
+                    const int row = 16 * (wid + 8 * i) + 4 * (lane >> 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) R[(row + e) * 18 + cc] = acc[i][n][e];
+                }
+        }
+        if (wid == nt0 || wid == nt0 + 1) {
+            const int cc = 16 * wid + (lane & 15) - c0;
+            if (cc >= 0 && cc < 18) {
+#pragma unroll
+                for (int s_ = 0; s_ < CQM_RS; ++s_)
+                    if (s_ < r) {
+                        const int row = 16 * (8 * q + s_) + 4 * (lane >> 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) R[(row + e) * 18 + cc] = accs[s_][e];
+                    }
+            }
+        }
+        __syncthreads();
+        const int nk = a.length[k];
+        const unsigned int inc = a.phase_inc[k];
+        const int half = nk >> 1;
+        const int hq = (half + H - 1) >> hshift;
+        const int eq = (nk - half) >> hshift;
+        const float inv_nk = 1.0f / (float)nk;
+        // block start phases (integer-exact): e^{-i phi jH} and e^{+-i theta (jH + N_k/2)}
+        for (int j = tid; j < nblk; j += 512) {
+            const unsigned int ms = (unsigned int)j << hshift;
+            const float turns = (float)(ms * inc) * 2.3283064365386963e-10f;
+            const amt_v2 osc = amt_v2{__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)};
+            const float wt = (float)((int)(((long)ms + half) % nk)) * inv_nk;
+            const amt_v2 wp = amt_v2{__builtin_amdgcn_cosf(wt), __builtin_amdgcn_sinf(wt)};
+            const amt_v2 op = cm_mul(osc, wp), om = cm_mul(osc, amt_v2{wp.x, -wp.y});
+            float *rj = R + j * 18;
+#pragma unroll
+            for (int set = 0; set < 3; ++set) {
+                float *p = rj + 6 * set;
+                const amt_v2 s0 = cm_mul(amt_v2{p[0], p[1]}, osc) * unscale;
+                const amt_v2 s1 = cm_mul(amt_v2{p[2], p[3]}, op) * unscale;
+                const amt_v2 s2 = cm_mul(amt_v2{p[4], p[5]}, om) * unscale;
+                p[0] = s0.x; p[1] = s0.y; p[2] = s1.x; p[3] = s1.y; p[4] = s2.x; p[5] = s2.y;
+            }
+        }
+        __syncthreads();
+        if (tid < 192) {                             // PF[i] = sum_{j < i} F_j in f64 (as in cqt_blocks_kernel)
+            const int e = tid >> 5, l = tid & 31;
+            const int per = (nblk + 31) >> 5;
+            const int i0 = min(l * per, nblk), i1 = min(i0 + per, nblk);
+            double sum = 0.0;
+            for (int i = i0; i < i1; ++i) sum += (double)R[i * 18 + e];
+            double v = sum;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const double u = __shfl_up(v, off, 32);
+                if (l >= off) v += u;
+            }
+            double run = v - sum;
+            if (l == 0) pf[e] = 0.0;
+            for (int i = i0; i < i1; ++i) {
+                run += (double)R[i * 18 + e];
+                pf[(size_t)(i + 1) * 6 + e] = run;
+            }
+        }
+        __syncthreads();
+        const float scale = 2.0f / sqrtf((float)nk);
+        for (int t = tid; t < a.T; t += 512) {
+            const int js = t - hq, je = t + eq;
+            const int i0 = min(max(js, 0), nblk), i1 = min(max(je, 0), nblk);
+            float sfr[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                float v = (float)(pf[(size_t)i1 * 6 + e] - pf[(size_t)i0 * 6 + e]);
+                if (je >= 0 && je < nblk) v += R[je * 18 + 12 + e];
+                if (js >= 0 && js < nblk) v -= R[js * 18 + 6 + e];
+                sfr[e] = v;
+            }
+            const float dt = (float)((int)(((long)t << hshift) % nk)) * inv_nk;
+            const float sd = __builtin_amdgcn_sinf(dt), cd = __builtin_amdgcn_cosf(dt);
+            const float ar = cd * sfr[2] + sd * sfr[3], ai = cd * sfr[3] - sd * sfr[2];
+            const float br = cd * sfr[4] - sd * sfr[5], bi = cd * sfr[5] + sd * sfr[4];
+            const float re = 0.5f * sfr[0] - 0.25f * (ar + br);
+            const float im = 0.5f * sfr[1] - 0.25f * (ai + bi);
+            vmax = fmaxf(vmax, sqrtf(re * re + im * im) * scale);
+        }
+        __syncthreads();                             // R / pf are rewritten for the next bin
+    }
+    vmax = wave_max(vmax);
+    if (lane == 0) atomicMax(a.out_max + b, __float_as_uint(vmax));
+}
+
 // Fallback for signals whose block sums do not fit the LDS (a whole song handed to slice_C): every requested
 // frame summed directly over its own N_k samples, one workgroup per (bin, window).  Any L; 8 N_k sample visits.
 __global__ __launch_bounds__(256) void cqt_slices_direct_kernel(amt_cqt_args a) {
@@ -434,6 +756,69 @@ extern "C" int amt_cqt_window_max(const float *wave, int B, int L, size_t wave_s
         cqt_blocks_kernel<false, true><<<dim3(n_bins, B), 256, 4 * CM_STAGE * sizeof(float), st>>>(wave, phase_inc, length,
                                                                                                    coef, a);
     }
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- MFMA form: geometry, table, launch ---------------------------------------------------------------------------
+static int cqm_geometry(int L, int hop, int *hshift, int *nblk, int *q, int *r) {
+    if (!amt_is_pow2(hop) || hop < 256 || hop > 2048) return AMT_E_UNSUPPORTED;
+    *hshift = 0;
+    while ((1 << *hshift) < hop) ++*hshift;
+    *nblk = (L + hop - 1) / hop;
+    const int n_mt = (*nblk + 15) / 16;
+    *q = n_mt / 8; *r = n_mt % 8;
+    if (*r > CQM_RS) { *q += 1; *r = 0; }
+    if (*q > CQM_MT) return AMT_E_UNSUPPORTED;                 // more blocks than the wave-private slabs hold: VALU form
+    return AMT_OK;
+}
+
+extern "C" size_t amt_cqt_mfma_table_bytes(int hop, int n_bins) {
+    if (!amt_is_pow2(hop) || hop < 256 || hop > 2048 || n_bins <= 0) return 0;
+    const size_t groups = (size_t)(n_bins + CQM_BINS - 1) / CQM_BINS;
+    return groups * (size_t)(hop >> 5) * (2 * 128 * 32) * sizeof(_Float16);
+}
+
+extern "C" int amt_cqt_mfma_table(const uint32_t *phase_inc, const int32_t *length, int n_bins, int hop, void *table,
+                                  void *stream) {
+    if (!phase_inc || !length || !table || n_bins <= 0) return AMT_E_INVALID;
+    const size_t bytes = amt_cqt_mfma_table_bytes(hop, n_bins);
+    if (!bytes) return AMT_E_UNSUPPORTED;
+    int hshift = 0;
+    while ((1 << hshift) < hop) ++hshift;
+    const size_t n_total = bytes / sizeof(_Float16) / 2;       // one thread per (h, l) pair
+    cqt_mfma_table_kernel<<<(unsigned)((n_total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        phase_inc, length, n_bins, hop, hshift, (_Float16 *)table, n_total);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_cqt_window_max_mfma(const float *wave, int B, int L, size_t wave_stride, int hop,
+                                       const uint32_t *phase_inc, const int32_t *length, const void *table, int n_bins,
+                                       float *out_max, float *amax_scratch, void *stream) {
+    if (!wave || !phase_inc || !length || !table || !out_max || !amax_scratch) return AMT_E_INVALID;
+    if (B <= 0 || L <= 0 || n_bins <= 0) return AMT_E_INVALID;
+    if (wave_stride < (size_t)L) return AMT_E_SHAPE;
+    CqmArgs a{};
+    if (cqm_geometry(L, hop, &a.hshift, &a.nblk, &a.q, &a.r) != AMT_OK) return AMT_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_ops = (size_t)(8 * 2 * 64 * 32 + 2 * 2 * 32 * 32 + 2 * 2 * 128 * 32) * sizeof(_Float16);
+    const size_t nrow = 16 * (size_t)(8 * a.q + a.r);
+    const size_t lds_epi = ((nrow * 18 * 4 + 15) & ~(size_t)15) + ((size_t)a.nblk + 1) * 6 * sizeof(double);
+    const size_t lds = lds_ops > lds_epi ? lds_ops : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_max_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          159 * 1024));
+        attr_set = true;
+    }
+    AMT_HIP_CHECK(hipMemsetAsync(out_max, 0, (size_t)B * sizeof(float), st));
+    cqt_amax_kernel<<<B, 256, 0, st>>>(wave, wave_stride, L, amax_scratch);
+    a.wave = wave; a.wave_stride = wave_stride; a.phase_inc = phase_inc; a.length = length;
+    a.table = (const _Float16 *)table; a.amax = amax_scratch; a.out_max = (unsigned int *)out_max;
+    a.L = L; a.H = hop; a.T = 1 + L / hop; a.n_bins = n_bins; a.KS = hop >> 5;
+    const int groups = (n_bins + CQM_BINS - 1) / CQM_BINS;
+    cqt_max_mfma_kernel<<<dim3(groups, B), 512, lds, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

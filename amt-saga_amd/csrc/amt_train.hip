@@ -260,12 +260,15 @@ __global__ void bn_backward_kernel(const float *dy /* may alias dz */, const flo
         dz[i] = training ? gamma[c] * inv[c] * (dy[i] - sdy[c] * invM - zh * (sdyz[c] * invM)) : gamma[c] * inv[c] * dy[i];
     }
 }
+// The batch is normalised with the BIASED variance, but the moving variance absorbs the UNBIASED one: TensorFlow's
+// fused batch norm hands var * M / (M - 1) to the running average (Keras 2.2's own path multiplies by
+// M / (M - (1 + epsilon)): 1e-3 / M apart), M = the samples per channel of this batch.  `bessel` = M / (M - 1), 1 for M = 1.
 __global__ void moving_update_kernel(float *__restrict__ mm, float *__restrict__ mv, const float *__restrict__ mu,
-                                     const float *__restrict__ var, int C) {
+                                     const float *__restrict__ var, int C, float bessel) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     mm[c] = TR_BN_MOMENTUM * mm[c] + (1.0f - TR_BN_MOMENTUM) * mu[c];
-    mv[c] = TR_BN_MOMENTUM * mv[c] + (1.0f - TR_BN_MOMENTUM) * var[c];
+    mv[c] = TR_BN_MOMENTUM * mv[c] + (1.0f - TR_BN_MOMENTUM) * (var[c] * bessel);
 }
 __global__ void inv_from_var_kernel(const float *__restrict__ var, int C, float *__restrict__ inv) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,8 +860,12 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
     AMT_LAUNCH_CHECK();
     // ---------------- update -------------------------------------------------------------------
     for (Op &o : t->ops)
-        if (o.kind == OP_BN)
-            moving_update_kernel<<<(o.Cout + 63) / 64, 64, 0, st>>>(t->params[o.p2].w, t->params[o.p3].w, o.bmu, o.bvar, o.Cout);
+        if (o.kind == OP_BN) {
+            const Tensor &in = t->tensors[o.in0];
+            const double M = (double)B * in.H * in.W;
+            moving_update_kernel<<<(o.Cout + 63) / 64, 64, 0, st>>>(t->params[o.p2].w, t->params[o.p3].w, o.bmu, o.bvar, o.Cout,
+                                                                   M > 1.0 ? (float)(M / (M - 1.0)) : 1.0f);
+        }
     for (Param &p : t->params)
         if (p.trainable) adagrad_kernel<<<grid1(p.n), 256, 0, st>>>(p.w, p.g, p.acc, p.n, t->lr, t->eps);
     AMT_LAUNCH_CHECK();

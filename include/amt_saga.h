@@ -327,6 +327,21 @@ int amt_trainer_step(amt_trainer *trainer, const float *const *x, const float *y
 int amt_trainer_get_weights(amt_trainer *trainer, float *weights_host, size_t n_floats);
 int amt_trainer_get_grads(amt_trainer *trainer, float *grads_host, size_t n_floats);
 
+/* MFMA form of amt_cqt_window_max for batches of windows (np.max(mid_wf.slice_C(0, duration, n_frames, ...)),
+ * training.py:271-282, with each window standing for its song): the per-block sums as one split-fp16 GEMM per window
+ * against a per-bin phasor table on a bin-independent block grid (amt_cqt.hip).  Same definition, same result to the
+ * 1e-4 the VALU form is held to; hop a power of two in 256..2048 and at most 544 hop-blocks per window
+ * (AMT_E_UNSUPPORTED otherwise: use amt_cqt_window_max).
+ *   amt_cqt_mfma_table_bytes(hop, n_bins)   bytes of the device phasor table for a bin grid
+ *   amt_cqt_mfma_table(...)                 builds it (once per grid and hop)
+ *   amt_cqt_window_max_mfma(...)            out_max[b] = max over bins and frames 0 .. L / hop; amax_scratch: [B] f32 */
+size_t amt_cqt_mfma_table_bytes(int hop, int n_bins);
+int amt_cqt_mfma_table(const uint32_t *phase_inc, const int32_t *length, int n_bins, int hop, void *table,
+                       void *stream);
+int amt_cqt_window_max_mfma(const float *wave, int B, int L, size_t wave_stride, int hop,
+                            const uint32_t *phase_inc, const int32_t *length, const void *table, int n_bins,
+                            float *out_max, float *amax_scratch, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * Measurement probe (no reference counterpart; bench.py's roofline object).  Sustained rate of back-to-back
  * v_mfma_f32_16x16x32_f16 on register operands with `waves_per_simd` waves per SIMD on every CU, `iters` x 8

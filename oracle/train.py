@@ -7,8 +7,9 @@ Follows /root/reference/RDCNN.py: compile() with ``keras.optimizers.Adagrad()`` 
 Keras / TensorFlow are not available here, so their training semantics are restated from the Keras 2.2
 documentation and source as remembered -- PARITY UNPINNED against Keras itself:
   * BatchNormalization(training=True): normalise with the batch mean and the biased batch variance over
-    (N, H, W); epsilon 1e-3; moving statistics m <- 0.99 m + 0.01 batch (the biased variance is used for the
-    moving average too; TensorFlow's fused kernel applies Bessel's correction there -- not reproduced);
+    (N, H, W); epsilon 1e-3; moving statistics m <- 0.99 m + 0.01 batch, where the variance entering the moving
+    average is the UNBIASED one, var * M / (M - 1) (TensorFlow's fused batch norm; Keras 2.2's own path uses
+    M / (M - (1 + epsilon)), 1e-3 / M apart), M = samples per channel;
   * Adagrad: lr 0.01, a += g^2, p -= lr g / (sqrt(a) + 1e-7); the accumulators start at 0 in Keras 2.2 /
     tf.keras 1.13 and at 0.1 in tf.keras >= 1.14 -- a parameter here, default 0.1;
   * mean_squared_error: mean over the output axis, then over the batch; sparse_categorical_crossentropy
@@ -113,10 +114,12 @@ def forward_backward(w, cfg, xs, y, dtype=np.float64):
     w = {k: np.asarray(v, dtype=dtype) for k, v in w.items()}
     r = cfg['residual_layer_frequencies'][0] if cfg['residual_layer_frequencies'] else 0
     tapes, flats, stats = [], [], {}
+    counts = forward_backward.last_counts = {}          # samples per channel of every BN layer (Bessel's correction)
 
     def bn(z, prefix, tape):
         out, cache, mu, var = bn_fwd(z, w[prefix + '/gamma'], w[prefix + '/beta'])
         stats[prefix] = (mu, var)
+        counts[prefix] = z.size // z.shape[-1]
         tape.append(('bn', prefix, cache))
         return out
 
@@ -231,5 +234,7 @@ def train_on_batch(w, cfg, xs, y, acc=None, lr=0.01, eps=1e-7, dtype=np.float32,
     w2, acc2 = adagrad_step(w, g, acc, lr, eps, initial_accumulator)
     for prefix, (mu, var) in stats.items():
         w2[prefix + '/mean'] = (BN_MOMENTUM * np.asarray(w[prefix + '/mean'], dtype) + (1 - BN_MOMENTUM) * mu).astype(np.float32)
-        w2[prefix + '/var'] = (BN_MOMENTUM * np.asarray(w[prefix + '/var'], dtype) + (1 - BN_MOMENTUM) * var).astype(np.float32)
+        M = forward_backward.last_counts[prefix]
+        bessel = dtype(M / (M - 1.0)) if M > 1 else dtype(1.0)
+        w2[prefix + '/var'] = (BN_MOMENTUM * np.asarray(w[prefix + '/var'], dtype) + (1 - BN_MOMENTUM) * (var * bessel)).astype(np.float32)
     return loss, pred, w2, acc2

@@ -81,8 +81,21 @@ def keras_graph(cfg):
     for idx in range(len(nodes) - 1, -1, -1):            # creation order is a topological order
         for j in nodes[idx][3]:
             depth[j] = max(depth[j], depth[idx] + 1)
-    del out
-    order = sorted(range(len(nodes)), key=lambda k: (-depth[k], k))      # model.layers: by depth, ties by creation
+    # model.layers: by depth; layers of equal depth by Keras' traversal index -- _map_graph_network's build_map numbers
+    # a layer the first time a depth-first walk from the output reaches it, descending into a node's inbound layers
+    # in the order they were passed to the call (Add()([intermediate, layer_to]): the shortcut branch first).
+    # Written recursively here, on purpose differently from the product's exporter (amt_saga/keras_io.keras_layers).
+    seen = {}
+
+    def build_map(k):
+        if k in seen:
+            return
+        seen[k] = len(seen)
+        for j in nodes[k][3]:
+            build_map(j)
+    sys.setrecursionlimit(10000)
+    build_map(out)
+    order = sorted(range(len(nodes)), key=lambda k: (-depth[k], seen[k]))
     return [nodes[k] for k in order]
 
 

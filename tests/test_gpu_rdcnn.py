@@ -493,3 +493,73 @@ def test_small_topologies(env, case):
                                pool_layer_frequency=case['pf'],
                                residual_layer_frequencies=case['r'], weight_seed=77)
     _check_head(env, net, net.cfg, 6, 11, name='shallow %s k%s' % (case['shape'], case['k']))
+
+
+@pytest.mark.parametrize('hop,L,grids', [
+    (512, 512 * 40 + 123, ((27.5, 87, 12), (220.0, 60, 48), (2000.0, 24, 24))),
+    (512, 512 * 52, ((27.5, 40, 192),)),                       # filters 30 x longer than the window
+    (1024, 1024 * 21 + 7, ((55.0, 75, 12), (27.5, 24, 192))),
+    (256, 256 * 64 + 200, ((110.0, 48, 24),)),
+    (512, 300, ((2000.0, 12, 12),)),                           # shorter than one block
+])
+def test_cqt_window_max_mfma_form(env, hop, L, grids):
+    """amt_cqt_window_max_mfma (block sums as a split-fp16 GEMM against the phasor table on a bin-independent block
+    grid) against the same oracle and at the same 1e-4 as the VALU form -- filters from shorter than a hop to 30 x the
+    window, ragged lengths, a window 1e6 x louder and one 1e-6 x quieter than its neighbours (per-window operand
+    scaling), silence, a click -- and against the VALU form itself."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr = 44100
+    rng = np.random.default_rng(hop + L + 1)
+    t = np.arange(L) / sr
+    waves = [np.sin(2 * np.pi * 440 * t) * np.exp(-3 * t) + 0.3 * np.sin(2 * np.pi * 1000 * t + 1),
+             0.2 * rng.standard_normal(L) * (t > 0.2 * L / sr),
+             np.zeros(L),
+             np.sin(2 * np.pi * 61.7 * t) * 0.5 + 0.4 * (np.abs(t - 0.5 * L / sr) < 1e-4),
+             1e6 * (np.sin(2 * np.pi * 330 * t) + 0.1 * rng.standard_normal(L)),
+             1e-6 * (np.sin(2 * np.pi * 2500 * t) * np.exp(-t) + 0.05 * rng.standard_normal(L))]
+    wave = np.stack(waves).astype(np.float32)
+    wd = torch.from_numpy(wave).cuda()
+    for fmin, n_bins, bpo in grids:
+        inc, length, _ = ocqt.cqt_table(sr, fmin, n_bins, bpo)
+        table = audio.cqt_table(sr, fmin, n_bins, bpo, 'cuda')
+        got = audio.cqt_window_max(wd, table, hop, form='mfma').cpu().numpy()
+        valu = audio.cqt_window_max(wd, table, hop, form='valu').cpu().numpy()
+        for i in range(len(waves)):
+            ref = ocqt.cqt_window_max(wave[i], inc, length, hop)
+            assert abs(got[i] - ref) <= REL * ref, (fmin, n_bins, bpo, i, got[i], ref)
+            assert abs(got[i] - valu[i]) <= REL * max(valu[i], 1e-30), (fmin, i, got[i], valu[i])
+        assert got[2] == 0.0
+        # a second call is bit-identical (no float atomics: the max is order-independent)
+        again = audio.cqt_window_max(wd, table, hop, form='mfma').cpu().numpy()
+        assert np.array_equal(got, again)
+
+
+def test_cqt_window_max_mfma_full_window_all_normaliser_grids(env):
+    """Two 6 s windows (516 frames: 515 blocks = 32 M-tiles + 1 leftover split over the waves) on the pitch head's
+    87-bin normaliser grid vs the oracle, and on the 348- / 1392-bin grids against the VALU form (the oracle needs
+    minutes for those); unsupported geometries are refused, not silently mis-computed."""
+    from amt_saga import synth
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    p = env['hp'].Hyperparams(N=2048)
+    L = p.H * (p.timing_frames - 1)
+    wave = synth.make_windows(3, L, 6, (2, 4), (0,), p.sr)[0]
+    wh = wave.cpu().numpy()
+    f_lo = float(audio.midi_to_hz(p.pitch_low))
+    span = p.pitch_high - p.pitch_low
+    inc, length, _ = ocqt.cqt_table(p.sr, f_lo, span, 12)
+    table = audio.cqt_table(p.sr, f_lo, span, 12, 'cuda')
+    got = audio.cqt_window_max(wave, table, p.H, form='mfma').cpu().numpy()
+    for i in range(2):
+        ref = ocqt.cqt_window_max(wh[i], inc, length, p.H)
+        assert abs(got[i] - ref) <= REL * ref, (i, got[i], ref)
+    for mult in (4, 16):
+        tb = audio.cqt_table(p.sr, f_lo, span * mult, 12 * mult, 'cuda')
+        a = audio.cqt_window_max(wave, tb, p.H, form='mfma').cpu().numpy()
+        b = audio.cqt_window_max(wave, tb, p.H, form='valu').cpu().numpy()
+        assert np.abs(a - b).max() <= 3e-5 * b.max(), (mult, a, b)
+        assert np.array_equal(audio.cqt_window_max(wave, tb, p.H).cpu().numpy(), a)          # 'auto' takes the MFMA form
+    # a whole song (1700 blocks) does not fit the MFMA form's slabs: refused when forced, VALU form under 'auto'
+    song = torch.zeros((1, 1700 * 512 + 77), device='cuda')
+    with pytest.raises(ValueError):
+        audio.cqt_window_max(song, table, p.H, form='mfma')
+    assert float(audio.cqt_window_max(song, table, p.H)[0]) == 0.0

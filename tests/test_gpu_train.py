@@ -29,6 +29,14 @@ def _batch(cfg, B, seed):
     return xs, y
 
 
+def _opt(net):
+    """(lr, epsilon, initial accumulator) the product will train with: the Keras-generation triple, overridden by
+    the individual attributes (rdcnn.res_net.ADAGRAD_DEFAULTS)."""
+    lr0, eps0, acc0 = net.ADAGRAD_DEFAULTS[net.keras_optimizer_version]
+    return (getattr(net, 'learning_rate', lr0), getattr(net, 'adagrad_epsilon', eps0),
+            getattr(net, 'adagrad_initial_accumulator', acc0))
+
+
 def _to_act(net, y):
     return net._scale_output_to_activation(y) if net.output_classes == 1 else y
 
@@ -39,10 +47,9 @@ def _compare_step(env, net, xs, y, w_before, acc, tag):
     loss = net.metrics_train[-1][0]
     grads = net.gradients()
     o_loss, o_pred, g, stats = env['otr'].forward_backward(w_before, net.cfg, xs, _to_act(net, y), np.float32)
-    lr = getattr(net, 'learning_rate', 0.01)
-    o_loss2, _, w_after, acc2 = env['otr'].train_on_batch(w_before, net.cfg, xs, _to_act(net, y), acc=acc, lr=lr,
-                                                          dtype=np.float32,
-                                                          initial_accumulator=getattr(net, 'adagrad_initial_accumulator', 0.1))
+    lr, eps, acc0 = _opt(net)
+    o_loss2, _, w_after, acc2 = env['otr'].train_on_batch(w_before, net.cfg, xs, _to_act(net, y), acc=acc, lr=lr, eps=eps,
+                                                          dtype=np.float32, initial_accumulator=acc0)
     assert abs(loss - o_loss) <= 2e-5 * max(abs(o_loss), 1e-3), (tag, loss, o_loss)
     o_out = net._scale_activation_to_output(o_pred) if net.output_classes == 1 else o_pred
     assert np.abs(pred - o_out).max() <= 1e-4 * max(np.abs(o_out).max(), 1e-6), tag
@@ -72,7 +79,10 @@ def _compare_step(env, net, xs, y, w_before, acc, tag):
 @pytest.mark.parametrize('case', range(len(CASES)))
 def test_train_step_vs_oracle(env, case):
     net = env['rdcnn'].res_net(weight_seed=31 + case, calibrated=False, **CASES[case])
-    net.adagrad_initial_accumulator = 0.0 if case % 2 == 0 else 0.1      # Keras 2.2 / tf.keras >= 1.14
+    # both Keras generations' Adagrad defaults, as consistent triples (lr 0.01 with accumulator 0.1 is no
+    # version's default)
+    net.keras_optimizer_version = 'keras-2.2' if case % 2 == 0 else 'tf.keras-1.14'
+    assert _opt(net) == ((0.01, 1e-7, 0.0) if case % 2 == 0 else (0.001, 1e-7, 0.1))
     xs, y = _batch(net.cfg, 6, case)
     w0 = {k: v.copy() for k, v in net.weights.items()}
     w1, acc = _compare_step(env, net, xs, y, w0, None, 'step1')
@@ -114,9 +124,27 @@ def test_velocity_head_first_step_and_learning(env):
         for _ in range(40):
             net.train(xs[0], y)
         for _ in range(40):
-            loss, _, w, acc = env['otr'].train_on_batch(w, net.cfg, xs, _to_act(net, y), acc=acc, dtype=np.float32)
+            lr, eps, acc0 = _opt(net)
+            loss, _, w, acc = env['otr'].train_on_batch(w, net.cfg, xs, _to_act(net, y), acc=acc, lr=lr, eps=eps,
+                                                        dtype=np.float32, initial_accumulator=acc0)
             ref.append(loss)
         losses = [m[0] for m in net.metrics_train]
         assert losses[-1] < 0.15 * losses[0], (case, losses[0], losses[-1])
         # same trajectory as the oracle (rounding differences grow slowly over the steps)
         assert np.abs(np.array(losses) - np.array(ref)).max() <= 0.02 * losses[0], (case, losses[-3:], ref[-3:])
+
+
+def test_timing_head_train_on_batch_vs_oracle(env):
+    """The head that is 97 % of the flops, through one train_on_batch (RDCNN.py:503-526 via timing_classifier.py:13-36)
+    at the reference's default N = 4096 (20 x 258 input, 33 layers, 4 x 16 kernels, 2 x 8 pools, projected shortcuts at
+    layers 14 and 26), batch of 2: loss, predictions, every gradient, the Adagrad update and the moving statistics
+    against oracle/train.py -- the same bars as the shallow nets and the velocity head."""
+    p = env['hp'].Hyperparams(N=4096)
+    h = env['heads'].timming_classifier(p, calibrated=False)
+    assert h.cfg['input_shapes'][0] == (20, 258, 1) and h.cfg['convolutional_layer_count'] == 33
+    rng = np.random.default_rng(12)
+    x = (rng.random((2, 20, 258, 1)) ** 2).astype(np.float32)
+    gold = rng.uniform(0, 258, 2)                  # frames (the reference feeds seconds into a frames-ranged head, SURVEY 3.4b)
+    w0 = {k: v.copy() for k, v in h.weights.items()}
+    _compare_step(env, h, [x], gold, w0, None, 'timing N=4096 B=2')
+    assert len(h.metrics_train) == 1 and h.current_batch == 1

@@ -124,3 +124,108 @@ def test_save_checkpoint_name(tmp_path):
     p = net.save_checkpoint()
     assert os.path.basename(p) == 'checkpoint_pitch_500.h5' and hdf5.File(p).attrs('/')['keras_version'] == b'2.2.4-tf'
 
+
+
+def _rewrite(src, dst, rename):
+    """Copy a Keras weights file with its layers renamed by `rename` (dict old -> new); file order kept."""
+    by_layer, layers = keras_io.read_layers(src)
+    w = hdf5.Writer()
+    new_names = [rename.get(n, n) for n in layers]
+    w.group('/', {'layer_names': [n.encode() for n in new_names], 'backend': b'tensorflow', 'keras_version': b'2.2.4-tf'})
+    for old, new in zip(layers, new_names):
+        arrays = by_layer[old]
+        w.group('/' + new, {'weight_names': [('%s/%s:0' % (new, k)).encode() for k in arrays]})
+        for k, a in arrays.items():
+            w.dataset('/%s/%s/%s:0' % (new, new, k), a)
+    w.save(dst)
+
+
+def _offset_names(layers, offsets, drop_first_suffix=False):
+    import re
+    out = {}
+    for n in layers:
+        m = re.match(r'(.*)_(\d+)$', n)
+        cls, c = m.group(1), int(m.group(2))
+        c2 = c + offsets.get(cls, 0)
+        out[n] = cls if (drop_first_suffix and c2 == 1 and False) else '%s_%d' % (cls, c2)
+    return out
+
+
+@pytest.mark.parametrize('tag', sorted(gen.CASES))
+def test_import_when_counters_do_not_start_at_one(tmp_path, golden_dir, tag):
+    """Keras' automatic name counters are per PROCESS: a model built after another one (the second model of a
+    session, or the tower-2 layers of instrument_dual, which continue tower 1's counters) starts at conv2d_34,
+    batch_normalization_53, dense_3 ...  The importer orders by counter inside each class, so an offset -- a different
+    one per class -- must import bit-exactly; so must tf.keras 2.x naming, where the first instance of a class has no
+    suffix at all ('conv2d', then 'conv2d_1')."""
+    src = os.path.join(golden_dir, 'keras_weights_%s.h5' % tag)
+    kw = dict(gen.CASES[tag])
+    want = res_net(calibrated=False, **kw).weights
+    _, layers = keras_io.read_layers(src)
+    for case, rename in (
+            ('offsets', _offset_names(layers, {'conv2d': 33, 'batch_normalization': 52, 'dense': 2, 'activation': 35,
+                                               'add': 16, 'input': 1, 'flatten': 1, 'max_pooling2d': 2,
+                                               'average_pooling2d': 2, 'concatenate': 1})),
+            ('tf2', {n: (n.rsplit('_', 1)[0] if n.endswith('_1') else
+                         '%s_%d' % (n.rsplit('_', 1)[0], int(n.rsplit('_', 1)[1]) - 1)) for n in layers})):
+        dst = str(tmp_path / ('%s_%s.h5' % (tag, case)))
+        _rewrite(src, dst, rename)
+        kw2 = dict(kw); kw2['weight_seed'] = 999
+        net = res_net(calibrated=False, **kw2)
+        net.load_weights(dst)
+        for k in want:
+            assert np.array_equal(net.weights[k], want[k]), (case, k)
+
+
+def test_ambiguous_maps_are_rejected(tmp_path, golden_dir):
+    src = os.path.join(golden_dir, 'keras_weights_shallow.h5')
+    kw = dict(gen.CASES['shallow'])
+    # (a) a weighted layer of a class the builder never creates
+    dst = str(tmp_path / 'unknown.h5')
+    _rewrite(src, dst, {'conv2d_2': 'separable_conv2d_2'})
+    with pytest.raises(ValueError, match='weighted layer'):
+        res_net(calibrated=False, **kw).load_weights(dst)
+    # (b) two layers of one class that reduce to the same counter ('conv2d' and 'conv2d_0' both read as 0)
+    dst = str(tmp_path / 'dup.h5')
+    _rewrite(src, dst, {'conv2d_1': 'conv2d', 'conv2d_2': 'conv2d_0'})
+    with pytest.raises(ValueError, match='ambiguous creation order'):
+        res_net(calibrated=False, **kw).load_weights(dst)
+    # (c) one weighted layer too many
+    dst = str(tmp_path / 'extra.h5')
+    by_layer, layers = keras_io.read_layers(src)
+    w = hdf5.Writer()
+    names = layers + ['dense_9']
+    w.group('/', {'layer_names': [n.encode() for n in names], 'backend': b'tensorflow', 'keras_version': b'2.2.4-tf'})
+    for n in layers:
+        w.group('/' + n, {'weight_names': [('%s/%s:0' % (n, k)).encode() for k in by_layer[n]]})
+        for k, a in by_layer[n].items():
+            w.dataset('/%s/%s/%s:0' % (n, n, k), a)
+    w.group('/dense_9', {'weight_names': [b'dense_9/kernel:0', b'dense_9/bias:0']})
+    w.dataset('/dense_9/dense_9/kernel:0', np.zeros((300, 1), np.float32))
+    w.dataset('/dense_9/dense_9/bias:0', np.zeros((1,), np.float32))
+    w.save(dst)
+    with pytest.raises(ValueError, match='more'):
+        res_net(calibrated=False, **kw).load_weights(dst)
+
+
+def test_model_layers_order_at_a_projected_shortcut(golden_dir):
+    """keras.engine.network sorts layers of equal depth by its depth-first traversal index, and
+    Add()([intermediate, layer_to]) (RDCNN.py:335) lists the shortcut branch first: the 1x1 Conv2D of a projected
+    shortcut comes BEFORE the main branch's Conv2D of the same depth (the exporter used creation order).
+    Checked on the exporter's order and on the fixture the independent generator wrote."""
+    net = res_net(calibrated=False, **gen.CASES['shallow'])
+    order = [n for n, _ in keras_io.keras_layers(net.cfg)]
+    prefix = dict(keras_io.keras_layers(net.cfg))
+    by_prefix = {v: k for k, v in prefix.items() if v}
+    pos = {n: i for i, n in enumerate(order)}
+    # shortcut closing at layer 2 (from the 1-channel input: 1x1 conv + BN, no pooling): its 1x1 conv (created as
+    # conv2d_3) has the depth of the main branch's BN of layer 2 and precedes it
+    assert by_prefix['t0/sc2'] == 'conv2d_3' and pos['conv2d_3'] == pos[by_prefix['t0/bn2']] - 1
+    # shortcut closing at layer 4 (1x1 conv + average pooling + BN): its 1x1 conv (created AFTER conv 4, as conv2d_6)
+    # has the depth of conv 4 (conv2d_5) and precedes it; the pooling precedes BN 4, the shortcut's BN the activation
+    assert by_prefix['t0/sc4'] == 'conv2d_6' and by_prefix['t0/conv4'] == 'conv2d_5'
+    assert pos['conv2d_6'] == pos['conv2d_5'] - 1
+    assert pos['average_pooling2d_1'] == pos[by_prefix['t0/bn4']] - 1
+    assert pos[by_prefix['t0/scbn4']] == pos['activation_4'] - 1
+    _, file_order = keras_io.read_layers(os.path.join(golden_dir, 'keras_weights_shallow.h5'))
+    assert file_order == order
