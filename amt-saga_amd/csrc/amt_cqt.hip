@@ -12,6 +12,7 @@
 // H-sample blocks and every frame is a difference of two prefix sums of block sums plus one block head.
 // VALU / L1-bound; no MFMA.
 #include "amt_common.h"
+#include <cstdlib>
 
 #define AMT_CQT_MAXF 8
 
@@ -341,6 +342,7 @@ struct CqmArgs {
     const float *amax;                  // [B] max |x| of each window
     unsigned int *out_max;              // [B] float bits, zeroed by the caller
     int L, H, hshift, T, n_bins, nblk, q, r, KS;
+    int debug;                          // AMT_CQM_DEBUG (timing breakdown only): 1 no epilogue, 2 no MFMAs, 4 no commit
 };
 
 // table: column col of group g = bin g * CQM_BINS + col / 18, component col % 18 = set * 6 + kind * 2 + part
@@ -387,6 +389,21 @@ __global__ __launch_bounds__(256) void cqt_amax_kernel(const float *__restrict__
     if (threadIdx.x == 0) amax[blockIdx.x] = m;
 }
 
+// f64 inclusive scan step inside 16-lane rows by DPP (row_shr: lanes without a source add 0): VALU-only, where
+// __shfl_up goes through the LDS crossbar (ds_bpermute, ~100 cycles a step)
+template <int N>
+__device__ __forceinline__ double cqm_row_shr_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, false);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, false);
+    return v + __hiloint2double(shi, slo);
+}
+
+// Q = private M-tiles per wave (0..CQM_MT), R = leftover M-tiles (0..CQM_RS): compile-time, so that the staging and
+// MFMA loops are straight-line code (as run-time bounds the per-tile guards turned into branches around every load,
+// each with its own s_waitcnt vmcnt(0): the prefetch serialised into eight L2 round trips per k-step -- 91 ms per
+// 1024 windows on the 1392-bin grid against 65 for the same kernel with the guards compiled away).
+template <int Q, int R>
 __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cqm_smem[];
     _Float16 *a_priv = (_Float16 *)cqm_smem;                       // [8 waves][2 planes][64 rows][32]          64 KB
@@ -394,7 +411,8 @@ __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
     _Float16 *b_lds = a_shr + 2 * 2 * 32 * 32;                     // [2 buffers][2 planes][128 cols][32]       32 KB
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int g = blockIdx.x, b = blockIdx.y;
-    const int L = a.L, H = a.H, hshift = a.hshift, KS = a.KS, q = a.q, r = a.r, nblk = a.nblk;
+    const int L = a.L, H = a.H, hshift = a.hshift, KS = a.KS, nblk = a.nblk;
+    constexpr int q = Q;
     const float *x = a.wave + (size_t)b * a.wave_stride;
     // per-window operand scale: max |x| 2^sx in [2^11, 2^12)
     int sx = 0;
@@ -407,217 +425,291 @@ __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
     const float xs = ldexpf(1.0f, sx);
 
     typedef float cqm_f4u __attribute__((ext_vector_type(4), aligned(4)));
-    auto load4 = [&](int row, int col4, int c) -> cq_f4 {
-        const long m = (long)row * H + 32 * c + 4 * col4;
-        if (row < nblk && m + 3 < L) return *(const cqm_f4u *)(x + m);
-        cq_f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < nblk) {
-            if (m < L) v.x = x[m];
-            if (m + 1 < L) v.y = x[m + 1];
-            if (m + 2 < L) v.z = x[m + 2];
-        }
-        return v;
+    // Staging of four samples of block `row` at k-step c in two halves: addr4() / the raw 16-byte load (issued a whole
+    // k-step ahead, nothing but the load: any arithmetic on the loaded value at issue time makes the compiler wait for
+    // it there) and fix4() at commit time (zeros past the end of the signal / the last block; a group that straddles L
+    // -- only when L is not a multiple of 4 -- is shifted into place by selects).
+    const bool ragged = (L & 3) != 0;                // uniform
+    auto addr4 = [&](int row, int col4, int c) -> const cqm_f4u * {
+        const int m = (row << hshift) + 32 * c + 4 * col4;
+        const bool in = row < nblk && m < L;
+        const unsigned int off = in ? (unsigned int)min(m, L - 4) * 4u : 0u;
+        return (const cqm_f4u *)((const unsigned char *)x + off);
     };
+    auto fix4 = [&](cq_f4 v, int row, int col4, int c) -> cq_f4 {
+        const int m = (row << hshift) + 32 * c + 4 * col4;
+        const bool in = row < nblk && m < L;
+        if (ragged) {
+            const int sh = m - min(m, L - 4);        // 0..3 when `in`
+            const cq_f4 w = v;
+            v.x = sh <= 0 ? w.x : (sh == 1 ? w.y : (sh == 2 ? w.z : w.w));
+            v.y = sh <= 0 ? w.y : (sh == 1 ? w.z : (sh == 2 ? w.w : 0.f));
+            v.z = sh <= 0 ? w.z : (sh == 1 ? w.w : 0.f);
+            v.w = sh <= 0 ? w.w : 0.f;
+        }
+        const cq_f4 z = {0.f, 0.f, 0.f, 0.f};
+        return in ? v : z;
+    };
+    // x 2^sx = h + l with h = f16(v) rounded toward zero (v_cvt_pkrtz_f16_f32 converts and packs two values per
+    // instruction), l = f16(v - h): the residual of a truncation is below one ulp of h and l's 11 bits carry it to
+    // 2^-21 of |v| or better
+    typedef __fp16 cq_hp2 __attribute__((ext_vector_type(2)));
+    struct cq_pair4 { cq_hp2 a, b; };
     auto split_store = [&](cq_f4 v, _Float16 *ph, _Float16 *pl) {
         v *= xs;
-        cq_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        cq_h4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
-                   (_Float16)(v.w - (float)h.w)};
-        *(cq_h4 *)ph = h;
-        *(cq_h4 *)pl = l;
+        const cq_hp2 h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+        const cq_hp2 l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01.x, v.y - (float)h01.y);
+        const cq_hp2 l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23.x, v.w - (float)h23.y);
+        *(cq_pair4 *)ph = cq_pair4{h01, h23};
+        *(cq_pair4 *)pl = cq_pair4{l01, l23};
     };
-    cq_f4 apre[2 * CQM_MT], spre;
-    uint4 bpre[2];
-    const uint4 *tab4 = (const uint4 *)(a.table + (size_t)g * KS * (2 * 128 * 32));
+    cq_f4 apre[2 * (Q > 0 ? Q : 1)], spre = {0.f, 0.f, 0.f, 0.f};
+    const unsigned char *tabb = (const unsigned char *)(a.table + (size_t)g * KS * (2 * 128 * 32));
+    const int srow = 16 * (8 * q + (tid >> 7)) + ((tid & 127) >> 3);          // this thread's row of the leftover tiles
     auto fetch = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < CQM_MT; ++i)
-            if (i < q) {
-                const int row0 = 16 * (wid + 8 * i) + (lane >> 3);
-                apre[2 * i] = load4(row0, lane & 7, c);
-                apre[2 * i + 1] = load4(row0 + 8, lane & 7, c);
-            }
-        if (tid < 128 * r) spre = load4(16 * (8 * q + (tid >> 7)) + ((tid & 127) >> 3), tid & 7, c);
-        const uint4 *src = tab4 + (size_t)c * (2 * 128 * 32 * 2 / 16);
-        bpre[0] = src[tid];
-        bpre[1] = src[tid + 512];
+        for (int i = 0; i < Q; ++i) {
+            const int row0 = 16 * (wid + 8 * i) + (lane >> 3);
+            apre[2 * i] = *addr4(row0, lane & 7, c);
+            apre[2 * i + 1] = *addr4(row0 + 8, lane & 7, c);
+        }
+        if (R > 0 && tid < 128 * R) spre = *addr4(srow, tid & 7, c);
+        // the table slab of the k-step (16 KB, a plain copy) goes global -> LDS directly (LDS-DMA: no registers; a wave
+        // instruction lands 64 x 16 contiguous bytes), into the buffer the PREVIOUS k-step's MFMAs no longer read
+        const unsigned char *src = tabb + (size_t)c * (2 * 128 * 32 * 2);
+        unsigned char *dst = (unsigned char *)(b_lds + (size_t)(c & 1) * (2 * 128 * 32));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (wid * 2 + u) * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + (wid * 2 + u) * 1024), 16, 0, 0);
     };
-    auto commit = [&](int c) {                       // registers -> LDS (wave-private A; shared A / B into buffer c & 1)
+    auto commit = [&](int c) {                       // staged registers -> LDS (wave-private A; leftover tiles' A into buffer c & 1)
         _Float16 *ap = a_priv + (size_t)wid * (2 * 64 * 32);
 #pragma unroll
-        for (int i = 0; i < CQM_MT; ++i)
-            if (i < q) {
+        for (int i = 0; i < Q; ++i) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int rl = 16 * i + 8 * u + (lane >> 3);
-                    split_store(apre[2 * i + u], ap + rl * 32 + 4 * (lane & 7), ap + (64 + rl) * 32 + 4 * (lane & 7));
-                }
+            for (int u = 0; u < 2; ++u) {
+                const int rl = 16 * i + 8 * u + (lane >> 3);
+                const cq_f4 v = fix4(apre[2 * i + u], 16 * (wid + 8 * i) + 8 * u + (lane >> 3), lane & 7, c);
+                split_store(v, ap + rl * 32 + 4 * (lane & 7), ap + (64 + rl) * 32 + 4 * (lane & 7));
             }
-        if (tid < 128 * r) {
+        }
+        if (R > 0 && tid < 128 * R) {
             _Float16 *sp = a_shr + (size_t)(c & 1) * (2 * 32 * 32);
             const int rl = 16 * (tid >> 7) + ((tid & 127) >> 3);
-            split_store(spre, sp + rl * 32 + 4 * (tid & 7), sp + (32 + rl) * 32 + 4 * (tid & 7));
+            split_store(fix4(spre, srow, tid & 7, c), sp + rl * 32 + 4 * (tid & 7), sp + (32 + rl) * 32 + 4 * (tid & 7));
         }
-        uint4 *bd = (uint4 *)(b_lds + (size_t)(c & 1) * (2 * 128 * 32));
-        bd[tid] = bpre[0];
-        bd[tid + 512] = bpre[1];
     };
 
-    cq_f4 acc[CQM_MT][CQM_NT], accs[CQM_RS];
+    cq_f4 acc[Q > 0 ? Q : 1][CQM_NT], accs[R > 0 ? R : 1];
 #pragma unroll
-    for (int i = 0; i < CQM_MT; ++i)
+    for (int i = 0; i < (Q > 0 ? Q : 1); ++i)
 #pragma unroll
         for (int n = 0; n < CQM_NT; ++n) acc[i][n] = cq_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s_ = 0; s_ < CQM_RS; ++s_) accs[s_] = cq_f4{0.f, 0.f, 0.f, 0.f};
+    for (int s_ = 0; s_ < (R > 0 ? R : 1); ++s_) accs[s_] = cq_f4{0.f, 0.f, 0.f, 0.f};
 
     fetch(0);
     const int fr = (lane & 15) * 32 + 8 * (lane >> 4);               // fragment offset inside a [16][32] tile (halfs)
     for (int c = 0; c < KS; ++c) {
-        commit(c);
+        if (!(a.debug & 4)) commit(c);
         __syncthreads();
         if (c + 1 < KS) fetch(c + 1);
+        if (a.debug & 2) continue;
         const _Float16 *ap = a_priv + (size_t)wid * (2 * 64 * 32);
         const _Float16 *sp = a_shr + (size_t)(c & 1) * (2 * 32 * 32);
         const _Float16 *bp = b_lds + (size_t)(c & 1) * (2 * 128 * 32);
-        cq_h8 ah[CQM_MT], al[CQM_MT];
+        cq_h8 ah[Q > 0 ? Q : 1], al[Q > 0 ? Q : 1];
 #pragma unroll
-        for (int i = 0; i < CQM_MT; ++i)
-            if (i < q) {
-                ah[i] = *(const cq_h8 *)(ap + 16 * i * 32 + fr);
-                al[i] = *(const cq_h8 *)(ap + (64 + 16 * i) * 32 + fr);
-            }
+        for (int i = 0; i < Q; ++i) {
+            ah[i] = *(const cq_h8 *)(ap + 16 * i * 32 + fr);
+            al[i] = *(const cq_h8 *)(ap + (64 + 16 * i) * 32 + fr);
+        }
 #pragma unroll
         for (int n = 0; n < CQM_NT; ++n) {
+            if (Q == 0) break;
             const cq_h8 bh = *(const cq_h8 *)(bp + 16 * n * 32 + fr);
             const cq_h8 bl = *(const cq_h8 *)(bp + (128 + 16 * n) * 32 + fr);
 #pragma unroll
-            for (int i = 0; i < CQM_MT; ++i)
-                if (i < q) {
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][n], 0, 0, 0);
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][n], 0, 0, 0);
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][n], 0, 0, 0);
-                }
+            for (int i = 0; i < Q; ++i) {
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][n], 0, 0, 0);
+            }
         }
         // leftover M-tiles: this wave takes N-tile `wid` of each
-        {
+        if (R > 0) {
             const cq_h8 bh = *(const cq_h8 *)(bp + 16 * wid * 32 + fr);
             const cq_h8 bl = *(const cq_h8 *)(bp + (128 + 16 * wid) * 32 + fr);
 #pragma unroll
-            for (int s_ = 0; s_ < CQM_RS; ++s_)
-                if (s_ < r) {
-                    const cq_h8 sh = *(const cq_h8 *)(sp + 16 * s_ * 32 + fr);
-                    const cq_h8 sl = *(const cq_h8 *)(sp + (32 + 16 * s_) * 32 + fr);
-                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bh, accs[s_], 0, 0, 0);
-                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bl, accs[s_], 0, 0, 0);
-                    accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sl, bh, accs[s_], 0, 0, 0);
-                }
+            for (int s_ = 0; s_ < R; ++s_) {
+                const cq_h8 sh = *(const cq_h8 *)(sp + 16 * s_ * 32 + fr);
+                const cq_h8 sl = *(const cq_h8 *)(sp + (32 + 16 * s_) * 32 + fr);
+                accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bh, accs[s_], 0, 0, 0);
+                accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sh, bl, accs[s_], 0, 0, 0);
+                accs[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sl, bh, accs[s_], 0, 0, 0);
+            }
         }
     }
     __syncthreads();                                 // every wave is done with the operand buffers: reuse them below
+    if (a.debug & 1) {                               // timing breakdown only
+        float v = 0.f;
+        for (int i = 0; i < (Q > 0 ? Q : 1); ++i) for (int n = 0; n < CQM_NT; ++n) v += acc[i][n].x;
+        if (v == 12345.f) atomicMax(a.out_max + b, 1u);
+        return;
+    }
 
-    // ---- epilogue, bin by bin: raw block sums -> LDS, start phases, f64 prefix, frames ------------------------------
-    const int nrow = 16 * (8 * q + r);
-    float *R = (float *)cqm_smem;                    // [nrow][18]
-    double *pf = (double *)(cqm_smem + (((size_t)nrow * 18 * 4 + 15) & ~(size_t)15));      // [nblk + 1][6]
+    // ---- epilogue, bin by bin: raw block sums -> LDS, f64 prefix of the phase-corrected F, frames -----------------------
+    // Two sets of (raw sums Rb [nrow][18], prefix pf [nblk + 1][6] f64), alternating between bins: while three waves
+    // scan bin bb, a fourth evaluates the frames of bin bb - 1 that did not fit its 512-thread round (T = 516: four
+    // frames would otherwise cost every wave a second round), and the dump of bin bb + 1 needs no barrier of its own.
+    constexpr int nrow = 16 * (8 * Q + R);
+    constexpr size_t RB_BYTES = ((size_t)nrow * 18 * 4 + 15) & ~(size_t)15;
+    const size_t PF_BYTES = (((size_t)nblk + 1) * 6 * sizeof(double) + 15) & ~(size_t)15;
     const float unscale = ldexpf(1.0f, -sx) / CQM_TSCALE;
     float vmax = 0.f;
-    for (int bb = 0; bb < CQM_BINS; ++bb) {
-        const int k = g * CQM_BINS + bb;
-        if (k >= a.n_bins) break;                    // uniform
-        const int c0 = 18 * bb, nt0 = c0 >> 4;
+    int nk = 1, half = 0, hq = 0, eq = 0;            // of the bin whose scan / frames run now
+    unsigned int inc = 0;
+    float inv_nk = 1.f;
+    // v mod nk for 0 <= v < 2^24 (block starts + N_k/2 stay far below): quotient from the float reciprocal, corrected
+    // by one step either way -- a dozen instructions against ~40 for the integer division
+    auto umod = [&](unsigned int v) -> unsigned int {
+        int qv = (int)((float)v * inv_nk);
+        int rv = (int)v - qv * nk;
+        rv += rv < 0 ? nk : 0;
+        rv -= rv >= nk ? nk : 0;
+        return (unsigned int)rv;
+    };
+    // start phases of block j (integer-exact): osc = e^{-i phi jH}, wp = e^{+i theta (jH + N_k/2)}
+    auto anchors = [&](int j, amt_v2 &osc, amt_v2 &wp) {
+        const unsigned int ms = (unsigned int)j << hshift;
+        const float turns = (float)(ms * inc) * 2.3283064365386963e-10f;
+        osc = amt_v2{__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)};
+        const float wt = (float)umod(ms + (unsigned int)half) * inv_nk;
+        wp = amt_v2{__builtin_amdgcn_cosf(wt), __builtin_amdgcn_sinf(wt)};
+    };
+    auto set_bin = [&](int k) {
+        nk = a.length[k]; inc = a.phase_inc[k];
+        half = nk >> 1; hq = (half + H - 1) >> hshift; eq = (nk - half) >> hshift;
+        inv_nk = 1.0f / (float)nk;
+    };
+    auto frame = [&](int t, const float *Rb, const double *pf) -> float {
+        const int js = t - hq, je = t + eq;
+        const int i0 = min(max(js, 0), nblk), i1 = min(max(je, 0), nblk);
+        float sfr[6];
 #pragma unroll
-        for (int n = 0; n < CQM_NT; ++n) {
-            if (n != nt0 && n != nt0 + 1) continue;  // uniform
-            const int cc = 16 * n + (lane & 15) - c0;
-            if (cc < 0 || cc >= 18) continue;
+        for (int e = 0; e < 6; ++e) sfr[e] = (float)(pf[(size_t)i1 * 6 + e] - pf[(size_t)i0 * 6 + e]);
+        // the heads of the end block (+) and of the start block (-): raw sums x their block's start phases
 #pragma unroll
-            for (int i = 0; i < CQM_MT; ++i)
-                if (i < q) {
+        for (int side = 0; side < 2; ++side) {
+            const int j = side ? js : je;
+            if (j < 0 || j >= nblk) continue;
+            amt_v2 osc, wp;
+            anchors(j, osc, wp);
+            const amt_v2 op = cm_mul(osc, wp), om = cm_mul(osc, amt_v2{wp.x, -wp.y});
+            const float *p = Rb + j * 18 + (side ? 6 : 12);
+            const float sg = side ? -unscale : unscale;
+            const amt_v2 g0 = cm_mul(amt_v2{p[0], p[1]}, osc) * sg;
+            const amt_v2 g1 = cm_mul(amt_v2{p[2], p[3]}, op) * sg;
+            const amt_v2 g2 = cm_mul(amt_v2{p[4], p[5]}, om) * sg;
+            sfr[0] += g0.x; sfr[1] += g0.y; sfr[2] += g1.x; sfr[3] += g1.y; sfr[4] += g2.x; sfr[5] += g2.y;
+        }
+        const float dt = (float)umod((unsigned int)t << hshift) * inv_nk;
+        const float sd = __builtin_amdgcn_sinf(dt), cd = __builtin_amdgcn_cosf(dt);
+        const float ar = cd * sfr[2] + sd * sfr[3], ai = cd * sfr[3] - sd * sfr[2];
+        const float br = cd * sfr[4] - sd * sfr[5], bi = cd * sfr[5] + sd * sfr[4];
+        const float re = 0.5f * sfr[0] - 0.25f * (ar + br);
+        const float im = 0.5f * sfr[1] - 0.25f * (ai + bi);
+        return sqrtf(re * re + im * im) * (2.0f / sqrtf((float)nk));
+    };
+    const int nb_here = min(CQM_BINS, a.n_bins - g * CQM_BINS);      // bins of this group (>= 1)
+    for (int bb = 0; bb <= nb_here; ++bb) {
+        float *Rb = (float *)(cqm_smem + (size_t)(bb & 1) * (RB_BYTES + PF_BYTES));
+        double *pf = (double *)((unsigned char *)Rb + RB_BYTES);
+        const float *Rp = (const float *)(cqm_smem + (size_t)((bb ^ 1) & 1) * (RB_BYTES + PF_BYTES));     // previous bin's set
+        const double *pfp = (const double *)((const unsigned char *)Rp + RB_BYTES);
+        if (bb < nb_here) {                          // dump bin bb's 18 columns (no barrier needed first: the set was last
+            const int c0 = 18 * bb, nt0 = c0 >> 4;   // read two barriers ago)
+#pragma unroll
+            for (int n = 0; n < CQM_NT; ++n) {
+                if (n != nt0 && n != nt0 + 1) continue;  // uniform
+                const int cc = 16 * n + (lane & 15) - c0;
+                if (cc < 0 || cc >= 18) continue;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) {
                     const int row = 16 * (wid + 8 * i) + 4 * (lane >> 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) R[(row + e) * 18 + cc] = acc[i][n][e];
+                    for (int e = 0; e < 4; ++e) Rb[(row + e) * 18 + cc] = acc[i][n][e];
                 }
-        }
-        if (wid == nt0 || wid == nt0 + 1) {
-            const int cc = 16 * wid + (lane & 15) - c0;
-            if (cc >= 0 && cc < 18) {
+            }
+            if (R > 0 && (wid == nt0 || wid == nt0 + 1)) {
+                const int cc = 16 * wid + (lane & 15) - c0;
+                if (cc >= 0 && cc < 18) {
 #pragma unroll
-                for (int s_ = 0; s_ < CQM_RS; ++s_)
-                    if (s_ < r) {
+                    for (int s_ = 0; s_ < R; ++s_) {
                         const int row = 16 * (8 * q + s_) + 4 * (lane >> 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) R[(row + e) * 18 + cc] = accs[s_][e];
+                        for (int e = 0; e < 4; ++e) Rb[(row + e) * 18 + cc] = accs[s_][e];
                     }
+                }
             }
         }
         __syncthreads();
-        const int nk = a.length[k];
-        const unsigned int inc = a.phase_inc[k];
-        const int half = nk >> 1;
-        const int hq = (half + H - 1) >> hshift;
-        const int eq = (nk - half) >> hshift;
-        const float inv_nk = 1.0f / (float)nk;
-        // block start phases (integer-exact): e^{-i phi jH} and e^{+-i theta (jH + N_k/2)}
-        for (int j = tid; j < nblk; j += 512) {
-            const unsigned int ms = (unsigned int)j << hshift;
-            const float turns = (float)(ms * inc) * 2.3283064365386963e-10f;
-            const amt_v2 osc = amt_v2{__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)};
-            const float wt = (float)((int)(((long)ms + half) % nk)) * inv_nk;
-            const amt_v2 wp = amt_v2{__builtin_amdgcn_cosf(wt), __builtin_amdgcn_sinf(wt)};
-            const amt_v2 op = cm_mul(osc, wp), om = cm_mul(osc, amt_v2{wp.x, -wp.y});
-            float *rj = R + j * 18;
+        if (bb < nb_here && wid < 3) {
+            // PF[i] = sum_{j < i} F_j in f64, one wave per complex component (z0, z+, z-): a lane owns PER consecutive
+            // blocks, applies their start phases (exact at its first block, a short recurrence after it), sums them;
+            // the 64 lane totals are scanned (DPP inside rows of 16, shuffles across), the lane writes its prefixes
+            set_bin(g * CQM_BINS + bb);
+            constexpr int PER = (nrow + 63) / 64;
+            const int j0 = lane * PER;
+            amt_v2 osc, wp, osc1, wp1;
+            anchors(min(j0, nblk), osc, wp);
+            anchors(1, osc1, wp1);                   // osc1 = e^{-i phi H}
+            const float wts = (float)umod((unsigned int)H) * inv_nk;
+            const amt_v2 wstep = amt_v2{__builtin_amdgcn_cosf(wts), __builtin_amdgcn_sinf(wts)};     // e^{+i theta H}, integer-exact
+            amt_v2 an = wid == 0 ? osc : (wid == 1 ? cm_mul(osc, wp) : cm_mul(osc, amt_v2{wp.x, -wp.y}));
+            const amt_v2 st = wid == 0 ? osc1 : (wid == 1 ? cm_mul(osc1, wstep) : cm_mul(osc1, amt_v2{wstep.x, -wstep.y}));
+            amt_v2 z[PER];
+            double sr = 0.0, si = 0.0;
 #pragma unroll
-            for (int set = 0; set < 3; ++set) {
-                float *p = rj + 6 * set;
-                const amt_v2 s0 = cm_mul(amt_v2{p[0], p[1]}, osc) * unscale;
-                const amt_v2 s1 = cm_mul(amt_v2{p[2], p[3]}, op) * unscale;
-                const amt_v2 s2 = cm_mul(amt_v2{p[4], p[5]}, om) * unscale;
-                p[0] = s0.x; p[1] = s0.y; p[2] = s1.x; p[3] = s1.y; p[4] = s2.x; p[5] = s2.y;
+            for (int i = 0; i < PER; ++i) {
+                const int j = j0 + i;
+                const int jc = min(j, nrow - 1);
+                const amt_v2 raw = amt_v2{Rb[jc * 18 + 2 * wid], Rb[jc * 18 + 2 * wid + 1]};
+                z[i] = j < nblk ? cm_mul(raw, an) * unscale : amt_v2{0.f, 0.f};
+                sr += (double)z[i].x; si += (double)z[i].y;
+                an = cm_mul(an, st);
             }
+            double vr = sr, vi = si;
+            vr = cqm_row_shr_add<1>(vr); vi = cqm_row_shr_add<1>(vi);
+            vr = cqm_row_shr_add<2>(vr); vi = cqm_row_shr_add<2>(vi);
+            vr = cqm_row_shr_add<4>(vr); vi = cqm_row_shr_add<4>(vi);
+            vr = cqm_row_shr_add<8>(vr); vi = cqm_row_shr_add<8>(vi);
+            {   // totals of the rows before this lane's row: lane 15 / 31 / 47 hold the row sums
+                const double r0 = __shfl(vr, 15, 64), r1 = __shfl(vr, 31, 64), r2 = __shfl(vr, 47, 64);
+                const double i0_ = __shfl(vi, 15, 64), i1_ = __shfl(vi, 31, 64), i2_ = __shfl(vi, 47, 64);
+                const int row = lane >> 4;
+                vr += (row > 0 ? r0 : 0.0) + (row > 1 ? r1 : 0.0) + (row > 2 ? r2 : 0.0);
+                vi += (row > 0 ? i0_ : 0.0) + (row > 1 ? i1_ : 0.0) + (row > 2 ? i2_ : 0.0);
+            }
+            double rr = vr - sr, ri = vi - si;       // blocks before this lane's run
+            if (lane == 0) { pf[2 * wid] = 0.0; pf[2 * wid + 1] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = j0 + i;
+                rr += (double)z[i].x; ri += (double)z[i].y;
+                if (j < nblk) { pf[(size_t)(j + 1) * 6 + 2 * wid] = rr; pf[(size_t)(j + 1) * 6 + 2 * wid + 1] = ri; }
+            }
+        } else if (bb > 0 && wid == 3) {
+            // frames 512 .. T-1 of the previous bin, from its (still intact) set
+            set_bin(g * CQM_BINS + bb - 1);
+            for (int t = 512 + lane; t < a.T; t += 64) vmax = fmaxf(vmax, frame(t, Rp, pfp));
         }
         __syncthreads();
-        if (tid < 192) {                             // PF[i] = sum_{j < i} F_j in f64 (as in cqt_blocks_kernel)
-            const int e = tid >> 5, l = tid & 31;
-            const int per = (nblk + 31) >> 5;
-            const int i0 = min(l * per, nblk), i1 = min(i0 + per, nblk);
-            double sum = 0.0;
-            for (int i = i0; i < i1; ++i) sum += (double)R[i * 18 + e];
-            double v = sum;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const double u = __shfl_up(v, off, 32);
-                if (l >= off) v += u;
-            }
-            double run = v - sum;
-            if (l == 0) pf[e] = 0.0;
-            for (int i = i0; i < i1; ++i) {
-                run += (double)R[i * 18 + e];
-                pf[(size_t)(i + 1) * 6 + e] = run;
-            }
+        if (bb < nb_here) {
+            set_bin(g * CQM_BINS + bb);
+            if (tid < a.T) vmax = fmaxf(vmax, frame(tid, Rb, pf));
         }
-        __syncthreads();
-        const float scale = 2.0f / sqrtf((float)nk);
-        for (int t = tid; t < a.T; t += 512) {
-            const int js = t - hq, je = t + eq;
-            const int i0 = min(max(js, 0), nblk), i1 = min(max(je, 0), nblk);
-            float sfr[6];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                float v = (float)(pf[(size_t)i1 * 6 + e] - pf[(size_t)i0 * 6 + e]);
-                if (je >= 0 && je < nblk) v += R[je * 18 + 12 + e];
-                if (js >= 0 && js < nblk) v -= R[js * 18 + 6 + e];
-                sfr[e] = v;
-            }
-            const float dt = (float)((int)(((long)t << hshift) % nk)) * inv_nk;
-            const float sd = __builtin_amdgcn_sinf(dt), cd = __builtin_amdgcn_cosf(dt);
-            const float ar = cd * sfr[2] + sd * sfr[3], ai = cd * sfr[3] - sd * sfr[2];
-            const float br = cd * sfr[4] - sd * sfr[5], bi = cd * sfr[5] + sd * sfr[4];
-            const float re = 0.5f * sfr[0] - 0.25f * (ar + br);
-            const float im = 0.5f * sfr[1] - 0.25f * (ai + bi);
-            vmax = fmaxf(vmax, sqrtf(re * re + im * im) * scale);
-        }
-        __syncthreads();                             // R / pf are rewritten for the next bin
     }
     vmax = wave_max(vmax);
     if (lane == 0) atomicMax(a.out_max + b, __float_as_uint(vmax));
@@ -804,21 +896,26 @@ extern "C" int amt_cqt_window_max_mfma(const float *wave, int B, int L, size_t w
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_ops = (size_t)(8 * 2 * 64 * 32 + 2 * 2 * 32 * 32 + 2 * 2 * 128 * 32) * sizeof(_Float16);
     const size_t nrow = 16 * (size_t)(8 * a.q + a.r);
-    const size_t lds_epi = ((nrow * 18 * 4 + 15) & ~(size_t)15) + ((size_t)a.nblk + 1) * 6 * sizeof(double);
+    const size_t lds_epi = 2 * (((nrow * 18 * 4 + 15) & ~(size_t)15) + ((((size_t)a.nblk + 1) * 6 * sizeof(double) + 15) & ~(size_t)15));
     const size_t lds = lds_ops > lds_epi ? lds_ops : lds_epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)cqt_max_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          159 * 1024));
-        attr_set = true;
+    void (*kern)(CqmArgs) = nullptr;
+    switch (a.q * 3 + a.r) {
+#define CQM_CASE(Q_, R_) case Q_ * 3 + R_: kern = cqt_max_mfma_kernel<Q_, R_>; break;
+        CQM_CASE(0, 1) CQM_CASE(0, 2)
+        CQM_CASE(1, 0) CQM_CASE(1, 1) CQM_CASE(1, 2) CQM_CASE(2, 0) CQM_CASE(2, 1) CQM_CASE(2, 2)
+        CQM_CASE(3, 0) CQM_CASE(3, 1) CQM_CASE(3, 2) CQM_CASE(4, 0) CQM_CASE(4, 1) CQM_CASE(4, 2)
+#undef CQM_CASE
+        default: return AMT_E_UNSUPPORTED;
     }
+    AMT_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     AMT_HIP_CHECK(hipMemsetAsync(out_max, 0, (size_t)B * sizeof(float), st));
     cqt_amax_kernel<<<B, 256, 0, st>>>(wave, wave_stride, L, amax_scratch);
     a.wave = wave; a.wave_stride = wave_stride; a.phase_inc = phase_inc; a.length = length;
     a.table = (const _Float16 *)table; a.amax = amax_scratch; a.out_max = (unsigned int *)out_max;
     a.L = L; a.H = hop; a.T = 1 + L / hop; a.n_bins = n_bins; a.KS = hop >> 5;
+    { const char *e = getenv("AMT_CQM_DEBUG"); a.debug = e ? atoi(e) : 0; }
     const int groups = (n_bins + CQM_BINS - 1) / CQM_BINS;
-    cqt_max_mfma_kernel<<<dim3(groups, B), 512, lds, st>>>(a);
+    kern<<<dim3(groups, B), 512, lds, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

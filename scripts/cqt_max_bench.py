@@ -15,16 +15,17 @@ f_lo = float(midi_to_hz(p.pitch_low))
 span = p.pitch_high - p.pitch_low
 for name, bpt in (('ref_C_1', 1), ('ref_C_inst', p.instrument_bins_per_tone), ('ref_C_foc', 4 * p.instrument_bins_per_tone)):
     tab = cqt_table(p.sr, f_lo, span * bpt, 12 * bpt, 'cuda')
-    cqt_window_max(wave, tab, p.H)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        out = cqt_window_max(wave, tab, p.H)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 3 * 1e3
-    sb = B * span * bpt * L
-    print('%-10s %5d bins  %7.1f ms / %d windows   %.2f T sample-bins/s   max %.4f' %
-          (name, span * bpt, ms, B, sb / ms / 1e9, float(out.max())), flush=True)
+    for form in ('valu', 'mfma'):
+        cqt_window_max(wave, tab, p.H, form=form)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = cqt_window_max(wave, tab, p.H, form=form)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        sb = B * span * bpt * L
+        print('%-10s %5d bins  %-4s form %7.1f ms / %d windows   %.2f T sample-bins/s   max %.4f' %
+              (name, span * bpt, form, ms, B, sb / ms / 1e9, float(out.max())), flush=True)
 
 # a whole song as one signal (transcribe.py / TranscriptionLoop.song_levels): 3 minutes
 Ls = 180 * p.sr
