@@ -119,6 +119,10 @@ def test_velocity_head_first_step_and_learning(env):
     assert pred.shape == (8, 1) and len(h.metrics_train) == 2 and h.metrics_train[1][0] < h.metrics_train[0][0]
     for case in (0, 1):
         net = env['rdcnn'].res_net(weight_seed=31 + case, calibrated=False, **CASES[case])
+        # an explicit optimiser setting for the learning demonstration (the attributes override the Keras-generation
+        # triple): with a zero initial accumulator the first Adagrad steps are +-lr for EVERY weight whatever its
+        # gradient, and forty of them do not bring a fresh net's loss down
+        net.learning_rate, net.adagrad_initial_accumulator = 0.01, 0.1
         xs, y = _batch(net.cfg, 8, 7)
         w, acc, ref = net.weights, None, []
         for _ in range(40):
