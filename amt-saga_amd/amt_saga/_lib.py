@@ -101,6 +101,10 @@ PROTOTYPES = {
     'amt_trainer_step': (C.c_int, [vp, C.POINTER(vp), vp, C.c_int, C.c_int, c_float_p, vp, vp]),
     'amt_trainer_get_weights': (C.c_int, [vp, vp, C.c_size_t]),
     'amt_trainer_get_grads': (C.c_int, [vp, vp, C.c_size_t]),
+    'amt_fftconv_create': (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, vp]),
+    'amt_fftconv_destroy': (C.c_int, [vp]),
+    'amt_fftconv_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'amt_fftconv_run': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]),
     'amt_probe_mfma_f16': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     'amt_rdcnn_profile': (C.c_int, [vp, C.c_int]),
     'amt_rdcnn_profile_read': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, c_int32_p, C.c_int]),

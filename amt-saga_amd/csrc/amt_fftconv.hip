@@ -1,0 +1,536 @@
+// FFT-domain form of the timing head's 4 x 16 convolutions on its large images (conv mode 3, experimental).
+//
+// Replaces, for the layers it is built for, Conv2D(32 -> 32, (4, 16), 'same') + BatchNormalization + sigmoid
+// (+ Add + BatchNormalization) of /root/reference/RDCNN.py:186-193 on the 20 x 516 (N = 2048) / 20 x 258 (N = 4096)
+// images of timing_classifier.py:13-36 -- the eleven layers per timing net that are 63 % of a C3 step in the direct
+// split-fp16 form (3.3 ms per 1024 windows and layer, at the chip's practical matrix-pipe ceiling: DESIGN 7).
+// The kernels are 16 taps long in the time direction; transformed along it, a layer needs 7 x fewer multiplies:
+//
+//   * rows of W <= 561 positions are transformed by 576-point COMPLEX FFTs of channel PAIRS z_p = a_2p + i a_2p+1
+//     (no real-FFT separation pass; 576 = 24 x 24: two register-resident 24-point transforms per thread around ONE
+//     LDS transposition);
+//   * per frequency pair (f, 576 - f) the layer is one real GEMM, K = 4 row taps x [Z_p[f], Z_p[576 - f]] = 256,
+//     N = [W_q[f], W_q[576 - f]] = 64, on the f16 matrix pipe in the same split-fp16 arithmetic as the direct form
+//     (h + l 2^-11, three MFMAs per product block, hi / lo accumulators); the (de)interleaving of the packed channels
+//     lives in the transformed kernel matrices (host, float64; scripts/fftconv_model.py is the numpy model);
+//   * the inverse transform of W_q = Y_2q + i Y_2q+1 returns two real output channels per sequence, already in the
+//     register layout the next layer's forward transform starts from, so BN + sigmoid (+ shortcut + BN) and the next
+//     forward transform run in the same kernel: between two such layers the activations never exist in HBM in the
+//     spatial domain unless a later shortcut reads them.
+//
+// Frequency tensors: Xf / Yf [fp = 0 .. 288][b][h][64] f32, the 64 = side (f | 576 - f) x pair (16) x (re, im).
+#include "amt_fft.h"
+#include "amt_fftconv.h"
+#include <cmath>
+#include <vector>
+
+#define FC_NF 576
+#define FC_NP 289
+#define FC_PS 1160                      // dwords per channel pair in the LDS transposition buffer (576 complex + 8 pad)
+#define FC_THREADS 384                  // 16 channel pairs x 24
+#define FC_LSCALE 2048.0f
+
+typedef _Float16 fc_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fc_h4 __attribute__((ext_vector_type(4)));
+typedef float fc_f4 __attribute__((ext_vector_type(4)));
+
+// e^{-2 pi i m / 24}, m = 0 .. 14
+__device__ static const float fc_w24[15][2] = {
+    {1.0f, 0.0f}, {0.96592582628906829f, -0.25881904510252076f}, {0.86602540378443865f, -0.5f},
+    {0.70710678118654752f, -0.70710678118654752f}, {0.5f, -0.86602540378443865f},
+    {0.25881904510252076f, -0.96592582628906829f}, {0.0f, -1.0f}, {-0.25881904510252076f, -0.96592582628906829f},
+    {-0.5f, -0.86602540378443865f}, {-0.70710678118654752f, -0.70710678118654752f},
+    {-0.86602540378443865f, -0.5f}, {-0.96592582628906829f, -0.25881904510252076f}, {-1.0f, 0.0f},
+    {-0.96592582628906829f, 0.25881904510252076f}, {-0.86602540378443865f, 0.5f}};
+
+// 24-point DFT in registers, natural order in and out: n = 3 n1 + n2, k = k1 + 8 k2; three 8-point transforms,
+// twiddles W24^{n2 k1}, eight 3-point transforms.  INV: the conjugate transform (no 1 / 24).
+template <bool INV>
+__device__ __forceinline__ void fc_fft24(float2 (&x)[24]) {
+    float2 y0[8], y1[8], y2[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) { y0[n1] = x[3 * n1]; y1[n1] = x[3 * n1 + 1]; y2[n1] = x[3 * n1 + 2]; }
+    dft_r<8, INV>(y0); dft_r<8, INV>(y1); dft_r<8, INV>(y2);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+        const float2 w1 = make_float2(fc_w24[k1][0], INV ? -fc_w24[k1][1] : fc_w24[k1][1]);
+        const float2 w2 = make_float2(fc_w24[2 * k1][0], INV ? -fc_w24[2 * k1][1] : fc_w24[2 * k1][1]);
+        y1[k1] = cmul(y1[k1], w1);
+        y2[k1] = cmul(y2[k1], w2);
+    }
+    const float s3 = 0.86602540378443865f;
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        const float2 a = y0[k1], b = y1[k1], c = y2[k1];
+        const float2 t1 = cadd(b, c);
+        const float2 t2 = make_float2(a.x - 0.5f * t1.x, a.y - 0.5f * t1.y);
+        const float2 d = make_float2(s3 * (b.x - c.x), s3 * (b.y - c.y));
+        // forward: X1 = t2 - i d, X2 = t2 + i d;  -i d = (d.y, -d.x)
+        const float2 md = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+        x[k1] = cadd(a, t1);
+        x[k1 + 8] = cadd(t2, md);
+        x[k1 + 16] = csub(t2, md);
+    }
+}
+
+struct FcRowArgs {
+    const float *in_sp; size_t in_stride;        // [B][H][W][32] spatial input (first layer of a chain), or null
+    const float *Yf;                             // [289][B][H][64] products of the GEMM (all other layers), or null
+    float *out_sp; size_t out_stride;            // spatial output [B][H][W][32], or null (no later reader)
+    float *Xf;                                   // [289][B][H][64] transform of the output for the next layer, or null
+    float *amaxf;                                // [B] max |Xf| per window (atomicMax, zeroed by the caller), with Xf
+    float *amax_out;                             // [B] max |spatial output| per window, or null
+    const float *s1, *t1, *s2, *t2;              // folded BN (+ conv bias); s2 / t2 null without a residual
+    const float *sc; size_t sc_stride;           // identity shortcut tensor [B][H][W][32], or null
+    const float *sc1; size_t sc1_stride;         // rank-1 shortcut: the one-channel network input [B][H][W] ...
+    const float *sc1_w, *sc1_s, *sc1_t;          // ... its 1x1 kernel and folded BN [32]
+    const float2 *tw;                            // [576] e^{-2 pi i m / 576}
+    int B, H, W;
+};
+
+__device__ __forceinline__ float fc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// One workgroup per image row (b, h).  IN_FREQ: inverse transform of Yf + epilogue; else the spatial input is loaded.
+// Then (a.Xf) the forward transform.
+template <bool IN_FREQ>
+__global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fc_smem[];
+    float *buf = fc_smem;                                   // [16][FC_PS]
+    float2 *tw = reinterpret_cast<float2 *>(fc_smem + 16 * FC_PS);
+    const int tid = threadIdx.x;
+    const int c16 = (tid >> 2) & 15;                        // channel pair
+    const int j24 = (tid & 3) + 4 * (tid >> 6);             // 0 .. 23
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    for (int i = tid; i < FC_NF; i += FC_THREADS) tw[i] = a.tw[i];
+    float2 x[24];
+    if (IN_FREQ) {
+        // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
+        const int k1 = j24;
+#pragma unroll
+        for (int k2 = 0; k2 < 24; ++k2) {
+            const int f = k1 + 24 * k2;
+            const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
+            x[k2] = *reinterpret_cast<const float2 *>(a.Yf + (((size_t)fp * a.B + b) * a.H + h) * 64 + side * 32 + 2 * c16);
+        }
+        fc_fft24<true>(x);
+        __syncthreads();                                    // the twiddle table is in place
+#pragma unroll
+        for (int n2 = 0; n2 < 24; ++n2) {
+            const float2 w = tw[n2 * k1];
+            const float2 v = cmul(x[n2], make_float2(w.x, -w.y));
+            *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (n2 * 24 + k1) * 2) = v;
+        }
+        __syncthreads();
+        // ---- second half: thread (q, n2 = j24) transforms over k1 -> n1: y[24 n1 + n2]
+        const int n2 = j24;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) x[k] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (n2 * 24 + k) * 2);
+        fc_fft24<true>(x);
+        // ---- epilogue: channels 2 c16 (real part) and 2 c16 + 1 (imaginary part), positions w = 24 n1 + n2
+        const int c0 = 2 * c16;
+        const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+        const bool res = a.s2 != nullptr;
+        const float s2a = res ? a.s2[c0] : 1.f, s2b = res ? a.s2[c0 + 1] : 1.f;
+        const float t2a = res ? a.t2[c0] : 0.f, t2b = res ? a.t2[c0 + 1] : 0.f;
+        float pw0 = 0.f, pw1 = 0.f, ps0 = 0.f, ps1 = 0.f, pt0 = 0.f, pt1 = 0.f;
+        if (a.sc1) {
+            pw0 = a.sc1_w[c0]; pw1 = a.sc1_w[c0 + 1]; ps0 = a.sc1_s[c0]; ps1 = a.sc1_s[c0 + 1];
+            pt0 = a.sc1_t[c0]; pt1 = a.sc1_t[c0 + 1];
+        }
+        const float inv_n = 1.0f / (float)FC_NF;
+        float vmax = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < 24; ++n1) {
+            const int w = 24 * n1 + n2;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < a.W) {
+                v.x = fc_sigmoid((x[n1].x * inv_n) * s1a + t1a);
+                v.y = fc_sigmoid((x[n1].y * inv_n) * s1b + t1b);
+                if (a.sc) {
+                    const float2 s = *reinterpret_cast<const float2 *>(a.sc + (size_t)b * a.sc_stride + ((size_t)h * a.W + w) * 32 + c0);
+                    v.x = (v.x + s.x) * s2a + t2a;
+                    v.y = (v.y + s.y) * s2b + t2b;
+                } else if (a.sc1) {
+                    const float xi = a.sc1[(size_t)b * a.sc1_stride + (size_t)h * a.W + w];
+                    v.x = (v.x + (fmaf(xi, pw0, 0.f) * ps0 + pt0)) * s2a + t2a;
+                    v.y = (v.y + (fmaf(xi, pw1, 0.f) * ps1 + pt1)) * s2b + t2b;
+                }
+                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+                if (a.out_sp)
+                    *reinterpret_cast<float2 *>(a.out_sp + (size_t)b * a.out_stride + ((size_t)h * a.W + w) * 32 + c0) = v;
+            }
+            x[n1] = v;
+        }
+        if (a.amax_out) {
+            vmax = wave_max(vmax);
+            if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
+        }
+        if (!a.Xf) return;
+        __syncthreads();                                    // every thread has read its column of `buf`
+    } else {
+        const int n2 = j24;
+#pragma unroll
+        for (int n1 = 0; n1 < 24; ++n1) {
+            const int w = 24 * n1 + n2;
+            x[n1] = w < a.W ? *reinterpret_cast<const float2 *>(a.in_sp + (size_t)b * a.in_stride + ((size_t)h * a.W + w) * 32 + 2 * c16)
+                            : make_float2(0.f, 0.f);
+        }
+        __syncthreads();                                    // the twiddle table is in place
+    }
+    // ---- forward: thread (p = c16, n2 = j24) transforms over n1 -> k1, twiddles, transposition, (p, k1 = j24) over n2 -> k2
+    {
+        const int n2 = j24;
+        fc_fft24<false>(x);
+#pragma unroll
+        for (int k1 = 0; k1 < 24; ++k1) {
+            const float2 v = cmul(x[k1], tw[n2 * k1]);
+            *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (k1 * 24 + n2) * 2) = v;
+        }
+        __syncthreads();
+        const int k1 = j24;
+#pragma unroll
+        for (int n = 0; n < 24; ++n) x[n] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (k1 * 24 + n) * 2);
+        fc_fft24<false>(x);
+        float fmax_ = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 24; ++k2) {
+            const int f = k1 + 24 * k2;
+            const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
+            float *dst = a.Xf + (((size_t)fp * a.B + b) * a.H + h) * 64 + 2 * c16;
+            *reinterpret_cast<float2 *>(dst + side * 32) = x[k2];
+            if (f == 0 || f == FC_NF / 2) *reinterpret_cast<float2 *>(dst + 32) = x[k2];     // self-paired bins fill both sides
+            fmax_ = fmaxf(fmax_, fmaxf(fabsf(x[k2].x), fabsf(x[k2].y)));
+        }
+        fmax_ = wave_max(fmax_);
+        if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amaxf) + b, __float_as_int(fmax_));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-frequency-pair GEMM: Yf[fp][b][h][n] = sum_{dy, s, p, e} Xf[fp][b][h + dy - 1][(s, p, e)] G[fp][(dy, s, p, e)][n]
+// 256 threads: wave (wm, wn) takes five of the chunk's ten 16-row M-tiles and two of the four N-tiles; its weight
+// fragments (8 k-steps x 2 N-tiles x h / l) stay in registers for the whole workgroup, the activations of a chunk of
+// eight windows (160 rows) are split into f16 h / l planes in LDS.
+// ---------------------------------------------------------------------------------------------
+#define FC_CW 8                         // windows per chunk
+#define FC_APITCH 72                    // halfs per staged row (64 + 8 pad: conflict-free 16-byte fragment reads)
+
+struct FcGemmArgs {
+    const float *Xf; float *Yf;
+    const float *amaxf;                  // [B]
+    const _Float16 *gw;                  // [289][8 k-steps][2 planes][64 n][32 k]
+    const int *gsw;                      // [289] weights of pair fp were scaled by 2^gsw
+    int B, H, nchunk_per_wg;
+};
+
+__device__ __forceinline__ int fc_scale_exp(float amax) {
+    int e = 0;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &e);
+    else return 0;
+    return min(max(13 - e, -90), 90);
+}
+
+__global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fcg_smem[];
+    _Float16 *ah = reinterpret_cast<_Float16 *>(fcg_smem);                   // [rows][FC_APITCH]
+    const int rows_cap = FC_CW * a.H;
+    _Float16 *al = ah + (size_t)rows_cap * FC_APITCH;
+    float *sa_s = reinterpret_cast<float *>(al + (size_t)rows_cap * FC_APITCH);      // [FC_CW] 2^sa, then [FC_CW] 2^-(sa + sw)
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fp = blockIdx.y;
+    const int H = a.H;
+    // weight fragments of this wave's two N-tiles, all eight k-steps, both planes
+    fc_h8 bh[8][2], bl[8][2];
+    {
+        const _Float16 *g = a.gw + (size_t)fp * (8 * 2 * 64 * 32);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = 16 * (2 * wn + nt) + (lane & 15);
+                bh[ks][nt] = *reinterpret_cast<const fc_h8 *>(g + ((size_t)(ks * 2 + 0) * 64 + n) * 32 + 8 * (lane >> 4));
+                bl[ks][nt] = *reinterpret_cast<const fc_h8 *>(g + ((size_t)(ks * 2 + 1) * 64 + n) * 32 + 8 * (lane >> 4));
+            }
+    }
+    const int sw = a.gsw[fp];
+    const int nchunks = (a.B + FC_CW - 1) / FC_CW;
+    for (int it = 0; it < a.nchunk_per_wg; ++it) {
+        const int chunk = blockIdx.x * a.nchunk_per_wg + it;
+        if (chunk >= nchunks) break;                        // uniform
+        const int b0 = chunk * FC_CW;
+        const int nw = min(FC_CW, a.B - b0);
+        const int rows = nw * H;
+        __syncthreads();                                    // the previous chunk's fragments have been read
+        if (tid < FC_CW) {
+            const int s_ = tid < nw ? fc_scale_exp(a.amaxf[b0 + tid]) : 0;
+            sa_s[tid] = ldexpf(1.0f, s_);
+            sa_s[FC_CW + tid] = ldexpf(1.0f, -(s_ + sw));
+        }
+        __syncthreads();
+        // stage: 16 float4 per row
+        const float *src = a.Xf + ((size_t)fp * a.B + b0) * H * 64;
+        for (int i = tid; i < rows * 16; i += 256) {
+            const int row = i >> 4, c4 = i & 15;
+            const fc_f4 v = *reinterpret_cast<const fc_f4 *>(src + (size_t)row * 64 + 4 * c4) * sa_s[row / H];
+            const fc_h4 hh = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const fc_h4 ll = {(_Float16)((v.x - (float)hh.x) * FC_LSCALE), (_Float16)((v.y - (float)hh.y) * FC_LSCALE),
+                              (_Float16)((v.z - (float)hh.z) * FC_LSCALE), (_Float16)((v.w - (float)hh.w) * FC_LSCALE)};
+            *reinterpret_cast<fc_h4 *>(ah + (size_t)row * FC_APITCH + 4 * c4) = hh;
+            *reinterpret_cast<fc_h4 *>(al + (size_t)row * FC_APITCH + 4 * c4) = ll;
+        }
+        __syncthreads();
+        const int n_mt = (rows + 15) >> 4;
+        for (int mt = wm; mt < n_mt; mt += 2) {
+            const int r = 16 * mt + (lane & 15);            // this lane's A row
+            const int hrow = r % H;
+            fc_f4 hi[2], lo[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) { hi[nt] = fc_f4{0.f, 0.f, 0.f, 0.f}; lo[nt] = fc_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const int hs = hrow + dy - 1;
+                const bool ok = r < rows && hs >= 0 && hs < H;
+                const int rs = ok ? r + dy - 1 : 0;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const int ks = 2 * dy + s_;
+                    fc_h8 fa = *reinterpret_cast<const fc_h8 *>(ah + (size_t)rs * FC_APITCH + 32 * s_ + 8 * (lane >> 4));
+                    fc_h8 fl = *reinterpret_cast<const fc_h8 *>(al + (size_t)rs * FC_APITCH + 32 * s_ + 8 * (lane >> 4));
+                    if (!ok) {
+                        fa = fc_h8{0, 0, 0, 0, 0, 0, 0, 0};
+                        fl = fa;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        hi[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, bh[ks][nt], hi[nt], 0, 0, 0);
+                        lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, bl[ks][nt], lo[nt], 0, 0, 0);
+                        lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, bh[ks][nt], lo[nt], 0, 0, 0);
+                    }
+                }
+            }
+            // D: column n = lane & 15, rows 4 (lane >> 4) + e
+            float *dst = a.Yf + ((size_t)fp * a.B + b0) * H * 64;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = 16 * (2 * wn + nt) + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ro = 16 * mt + 4 * (lane >> 4) + e;
+                    if (ro < rows) dst[(size_t)ro * 64 + n] = (hi[nt][e] + lo[nt][e] * (1.0f / FC_LSCALE)) * sa_s[FC_CW + ro / H];
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// Host side
+// =====================================================================================
+struct amt_fftconv_layer {
+    _Float16 *gw = nullptr;
+    int *gsw = nullptr;
+    float2 *tw = nullptr;
+    float *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;      // optional device copies (stand-alone entry)
+};
+
+static inline unsigned short fc_f16_bits(_Float16 h) { unsigned short b; memcpy(&b, &h, 2); return b; }
+
+int amt_fftconv_layer_create_internal(amt_fftconv_layer **out, const float *kernel /* [4][16][32][32] host */) {
+    if (!out || !kernel) return AMT_E_INVALID;
+    const int KH = 4, KW = 16, C = 32, P = 16, pl = (KW - 1) / 2;
+    amt_fftconv_layer *L = new amt_fftconv_layer();
+    std::vector<_Float16> gw((size_t)FC_NP * 8 * 2 * 64 * 32);
+    std::vector<int> gsw(FC_NP);
+    std::vector<double> G(256 * 64);
+    const double PI2 = 6.283185307179586476925286766559;
+    // Kf[fo][dy][ci][co] = sum_dx K[dy][dx][ci][co] e^{+2 pi i fo (dx - pl) / 576} for every fo (a [576 x 16] x [16 x 4096]
+    // complex product), so that Y[w] = IDFT(Af Kf)[w] is the 'same'-padded correlation of the layer
+    std::vector<double> cs(FC_NF), sn(FC_NF);
+    for (int m = 0; m < FC_NF; ++m) { cs[m] = cos(PI2 * m / FC_NF); sn[m] = sin(PI2 * m / FC_NF); }
+    const size_t KSZ = (size_t)KH * C * C;
+    std::vector<double> kfr((size_t)FC_NF * KSZ, 0.0), kfi((size_t)FC_NF * KSZ, 0.0);
+    for (int fo = 0; fo < FC_NF; ++fo)
+        for (int dx = 0; dx < KW; ++dx) {
+            const int m = (int)((((long)fo * (dx - pl)) % FC_NF + FC_NF) % FC_NF);
+            const double c_ = cs[m], s_ = sn[m];
+            for (int dy = 0; dy < KH; ++dy) {
+                const float *kp = kernel + (size_t)(dy * KW + dx) * C * C;
+                double *orr = kfr.data() + (size_t)fo * KSZ + (size_t)dy * C * C, *oii = kfi.data() + (size_t)fo * KSZ + (size_t)dy * C * C;
+                for (int e = 0; e < C * C; ++e) { orr[e] += kp[e] * c_; oii[e] += kp[e] * s_; }
+            }
+        }
+    for (int fp = 0; fp < FC_NP; ++fp) {
+        std::fill(G.begin(), G.end(), 0.0);
+        for (int t = 0; t < 2; ++t) {
+            const int fo = t == 0 ? fp : (FC_NF - fp) % FC_NF;
+            const double *kre = kfr.data() + (size_t)fo * KSZ, *kim = kfi.data() + (size_t)fo * KSZ;
+            const int s_z = t == 0 ? 0 : 1, s_c = t == 0 ? 1 : 0;
+            for (int dy = 0; dy < KH; ++dy)
+                for (int p = 0; p < P; ++p)
+                    for (int q = 0; q < P; ++q) {
+                        // cz[c] = (Kf[2p][c] - i Kf[2p+1][c]) / 2, cc[c] = (Kf[2p][c] + i Kf[2p+1][c]) / 2, c in {2q, 2q+1};
+                        // wz = cz[2q] + i cz[2q+1], wc = cc[2q] + i cc[2q+1]
+                        auto K = [&](int ci, int co, double &re, double &im) {
+                            re = kre[((size_t)dy * C + ci) * C + co]; im = kim[((size_t)dy * C + ci) * C + co];
+                        };
+                        double er0, ei0, er1, ei1, or0, oi0, or1, oi1;
+                        K(2 * p, 2 * q, er0, ei0); K(2 * p, 2 * q + 1, er1, ei1);
+                        K(2 * p + 1, 2 * q, or0, oi0); K(2 * p + 1, 2 * q + 1, or1, oi1);
+                        // cz[c] = (e - i o) / 2 = ((er + oi) + i (ei - or)) / 2;  cc[c] = (e + i o) / 2 = ((er - oi) + i (ei + or)) / 2
+                        const double cz0r = 0.5 * (er0 + oi0), cz0i = 0.5 * (ei0 - or0), cz1r = 0.5 * (er1 + oi1), cz1i = 0.5 * (ei1 - or1);
+                        const double cc0r = 0.5 * (er0 - oi0), cc0i = 0.5 * (ei0 + or0), cc1r = 0.5 * (er1 - oi1), cc1i = 0.5 * (ei1 + or1);
+                        // w = c0 + i c1
+                        const double wzr = cz0r - cz1i, wzi = cz0i + cz1r, wcr = cc0r - cc1i, wci = cc0i + cc1r;
+                        const int kz = ((dy * 2 + s_z) * P + p) * 2, kc = ((dy * 2 + s_c) * P + p) * 2, n = (t * P + q) * 2;
+                        G[(size_t)kz * 64 + n] += wzr; G[(size_t)(kz + 1) * 64 + n] += -wzi;
+                        G[(size_t)kz * 64 + n + 1] += wzi; G[(size_t)(kz + 1) * 64 + n + 1] += wzr;
+                        G[(size_t)kc * 64 + n] += wcr; G[(size_t)(kc + 1) * 64 + n] += wci;
+                        G[(size_t)kc * 64 + n + 1] += wci; G[(size_t)(kc + 1) * 64 + n + 1] += -wcr;
+                    }
+        }
+        double gmax = 0;
+        for (double v : G) gmax = std::max(gmax, std::fabs(v));
+        int sw = 0;
+        if (gmax > 0) { int e; (void)frexp(gmax, &e); sw = 4 - e; }       // max |G| 2^sw in [8, 16)
+        gsw[fp] = sw;
+        const double sc = ldexp(1.0, sw);
+        for (int k = 0; k < 256; ++k)
+            for (int n = 0; n < 64; ++n) {
+                const float v = (float)(G[(size_t)k * 64 + n] * sc);
+                _Float16 hh = (_Float16)v;
+                if (!(std::fabs(v) >= 6.103515625e-05f)) hh = (_Float16)0.0f;
+                const float rr = (v - (float)hh) * FC_LSCALE;
+                _Float16 ll = (_Float16)rr;
+                if (!(std::fabs(rr) >= 6.103515625e-05f)) ll = (_Float16)0.0f;
+                const int ks = k >> 5, kk = k & 31;
+                gw[(((size_t)fp * 8 + ks) * 2 + 0) * 64 * 32 + (size_t)n * 32 + kk] = hh;
+                gw[(((size_t)fp * 8 + ks) * 2 + 1) * 64 * 32 + (size_t)n * 32 + kk] = ll;
+            }
+    }
+    std::vector<float2> tw(FC_NF);
+    for (int m = 0; m < FC_NF; ++m) {
+        const double ang = -PI2 * m / FC_NF;
+        tw[m] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    hipError_t e = hipMalloc(&L->gw, gw.size() * sizeof(_Float16));
+    if (e == hipSuccess) e = hipMemcpy(L->gw, gw.data(), gw.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&L->gsw, gsw.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(L->gsw, gsw.data(), gsw.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&L->tw, tw.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(L->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        snprintf(amt_hip_err_buf, sizeof(amt_hip_err_buf), "fftconv upload: %s", hipGetErrorString(e));
+        amt_fftconv_layer_destroy_internal(L);
+        return AMT_E_HIP;
+    }
+    *out = L;
+    return AMT_OK;
+}
+
+void amt_fftconv_layer_destroy_internal(amt_fftconv_layer *L) {
+    if (!L) return;
+    for (void *p : {(void *)L->gw, (void *)L->gsw, (void *)L->tw, (void *)L->s1, (void *)L->t1, (void *)L->s2, (void *)L->t2})
+        if (p) (void)hipFree(p);
+    delete L;
+}
+
+size_t amt_fftconv_freq_floats(int B, int H) { return (size_t)FC_NP * B * H * 64; }
+
+static const size_t FC_ROW_LDS = (size_t)(16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+
+int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size_t in_stride, int B, int H, int W,
+                            float *Xf, float *amaxf, hipStream_t st) {
+    if (!L || !in_sp || !Xf || !amaxf || W + 15 > FC_NF) return AMT_E_INVALID;
+    static bool attr = false;
+    if (!attr) {
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
+        attr = true;
+    }
+    AMT_HIP_CHECK(hipMemsetAsync(amaxf, 0, (size_t)B * sizeof(float), st));
+    FcRowArgs a{};
+    a.in_sp = in_sp; a.in_stride = in_stride; a.Xf = Xf; a.amaxf = amaxf; a.tw = L->tw; a.B = B; a.H = H; a.W = W;
+    fc_row_kernel<false><<<B * H, FC_THREADS, FC_ROW_LDS, st>>>(a);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *amaxf, int B, int H, float *Yf, hipStream_t st) {
+    if (!L || !Xf || !Yf || !amaxf) return AMT_E_INVALID;
+    const size_t lds = (size_t)2 * FC_CW * H * FC_APITCH * sizeof(_Float16) + 2 * FC_CW * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const int nchunks = (B + FC_CW - 1) / FC_CW;
+    int per = 1;
+    while ((size_t)((nchunks + per - 1) / per) * FC_NP > 4096 && per < 16) per *= 2;      // ~2 resident rounds of workgroups
+    FcGemmArgs a{Xf, Yf, amaxf, L->gw, L->gsw, B, H, per};
+    fc_gemm_kernel<<<dim3((nchunks + per - 1) / per, FC_NP), 256, lds, st>>>(a);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_fftconv_inverse_epilogue(const amt_fftconv_layer *L, const float *Yf, const FcEpilogue &ep, int B, int H, int W,
+                                 float *out_sp, size_t out_stride, float *Xf_next, float *amaxf_next, float *amax_out,
+                                 hipStream_t st) {
+    if (!L || !Yf || !ep.s1 || !ep.t1 || (!out_sp && !Xf_next)) return AMT_E_INVALID;
+    if (Xf_next && !amaxf_next) return AMT_E_INVALID;
+    if (Xf_next) AMT_HIP_CHECK(hipMemsetAsync(amaxf_next, 0, (size_t)B * sizeof(float), st));
+    FcRowArgs a{};
+    a.Yf = Yf; a.out_sp = out_sp; a.out_stride = out_stride; a.Xf = Xf_next; a.amaxf = amaxf_next; a.amax_out = amax_out;
+    a.s1 = ep.s1; a.t1 = ep.t1; a.s2 = ep.s2; a.t2 = ep.t2; a.sc = ep.sc; a.sc_stride = ep.sc_stride;
+    a.sc1 = ep.sc1; a.sc1_stride = ep.sc1_stride; a.sc1_w = ep.sc1_w; a.sc1_s = ep.sc1_s; a.sc1_t = ep.sc1_t;
+    a.tw = L->tw; a.B = B; a.H = H; a.W = W;
+    fc_row_kernel<true><<<B * H, FC_THREADS, FC_ROW_LDS, st>>>(a);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- stand-alone C ABI entry (tests / microbenchmarks): one layer, spatial in, spatial out --------------------------
+extern "C" {
+
+int amt_fftconv_create(amt_fftconv_layer **layer, const float *kernel_host, const float *s1, const float *t1,
+                       const float *s2, const float *t2) {
+    if (!layer || !kernel_host || !s1 || !t1) return AMT_E_INVALID;
+    int rc = amt_fftconv_layer_create_internal(layer, kernel_host);
+    if (rc != AMT_OK) return rc;
+    amt_fftconv_layer *L = *layer;
+    auto up = [&](const float *h, float **d) -> hipError_t {
+        if (!h) return hipSuccess;
+        hipError_t e = hipMalloc(d, 32 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(*d, h, 32 * sizeof(float), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(s1, &L->s1);
+    if (e == hipSuccess) e = up(t1, &L->t1);
+    if (e == hipSuccess) e = up(s2, &L->s2);
+    if (e == hipSuccess) e = up(t2, &L->t2);
+    if (e != hipSuccess) { amt_fftconv_layer_destroy_internal(L); *layer = nullptr; return AMT_E_HIP; }
+    return AMT_OK;
+}
+
+int amt_fftconv_destroy(amt_fftconv_layer *layer) { amt_fftconv_layer_destroy_internal(layer); return AMT_OK; }
+
+size_t amt_fftconv_workspace_bytes(int B, int H) { return (2 * amt_fftconv_freq_floats(B, H) + 2 * (size_t)B) * sizeof(float); }
+
+int amt_fftconv_run(const amt_fftconv_layer *L, const float *in, const float *shortcut, int B, int H, int W, float *out,
+                    void *workspace, size_t workspace_bytes, int repeat_gemm, void *stream) {
+    if (!L || !in || !out || !workspace || B <= 0 || H <= 0 || W <= 0) return AMT_E_INVALID;
+    if (W + 15 > FC_NF) return AMT_E_UNSUPPORTED;
+    if (workspace_bytes < amt_fftconv_workspace_bytes(B, H)) return AMT_E_NOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    float *Xf = (float *)workspace, *Yf = Xf + amt_fftconv_freq_floats(B, H), *amaxf = Yf + amt_fftconv_freq_floats(B, H);
+    const size_t stride = (size_t)H * W * 32;
+    int rc = amt_fftconv_forward_fft(L, in, stride, B, H, W, Xf, amaxf, st);
+    for (int i = 0; i < (repeat_gemm > 0 ? repeat_gemm : 1) && rc == AMT_OK; ++i) rc = amt_fftconv_gemm(L, Xf, amaxf, B, H, Yf, st);
+    if (rc != AMT_OK) return rc;
+    FcEpilogue ep{};
+    ep.s1 = L->s1; ep.t1 = L->t1;
+    if (shortcut && L->s2) { ep.s2 = L->s2; ep.t2 = L->t2; ep.sc = shortcut; ep.sc_stride = stride; }
+    return amt_fftconv_inverse_epilogue(L, Yf, ep, B, H, W, out, stride, nullptr, nullptr, nullptr, st);
+}
+
+}  // extern "C"

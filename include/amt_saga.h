@@ -343,6 +343,21 @@ int amt_cqt_window_max_mfma(const float *wave, int B, int L, size_t wave_stride,
                             float *out_max, float *amax_scratch, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * FFT-domain form of ONE Conv2D(32 -> 32, (4, 16), 'same') + BatchNormalization + sigmoid (+ Add + BatchNormalization)
+ * layer of res_net (RDCNN.py:186-193) on an H x W image, W <= 561: the stand-alone entry the parity tests and the
+ * layer microbenchmark use; inside amt_rdcnn_forward the same kernels run chained (conv mode 3).
+ *   kernel_host [4][16][32][32] (kh, kw, cin, cout); s1, t1: folded BN (+ bias) [32]; s2, t2: the BN after the Add, or
+ *   NULL; in / shortcut / out: device [B][H][W][32]; workspace: amt_fftconv_workspace_bytes(B, H) of device memory.
+ * ------------------------------------------------------------------------ */
+typedef struct amt_fftconv_layer amt_fftconv_layer;
+int amt_fftconv_create(amt_fftconv_layer **layer, const float *kernel_host, const float *s1, const float *t1,
+                       const float *s2, const float *t2);
+int amt_fftconv_destroy(amt_fftconv_layer *layer);
+size_t amt_fftconv_workspace_bytes(int B, int H);
+int amt_fftconv_run(const amt_fftconv_layer *layer, const float *in, const float *shortcut, int B, int H, int W,
+                    float *out, void *workspace, size_t workspace_bytes, int repeat_gemm, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Measurement probe (no reference counterpart; bench.py's roofline object).  Sustained rate of back-to-back
  * v_mfma_f32_16x16x32_f16 on register operands with `waves_per_simd` waves per SIMD on every CU, `iters` x 8
  * MFMAs per wave and launch, best of `launches`; random_operands != 0: random non-zero f16 operands (the rate

@@ -1,0 +1,68 @@
+"""GPU parity of the FFT-domain form of one 4 x 16 convolution layer (amt_fftconv.hip, conv mode 3 of the RDCNN) against
+a float64 direct convolution + BN + sigmoid (+ shortcut + BN) in numpy -- the operator oracle/rdcnn.py applies layer by
+layer -- and against the float32 numpy result: the FFT form must sit as close to the float64 truth as float32 does."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _direct(a, k, dtype):
+    B, H, W, Ci = a.shape
+    KH, KW, _, Co = k.shape
+    pt, pl = (KH - 1) // 2, (KW - 1) // 2
+    ap = np.zeros((B, H + KH - 1, W + KW - 1, Ci), dtype)
+    ap[:, pt:pt + H, pl:pl + W] = a
+    y = np.zeros((B, H, W, Co), dtype)
+    kk = k.astype(dtype)
+    for dy in range(KH):
+        for dx in range(KW):
+            y += ap[:, dy:dy + H, dx:dx + W] @ kk[dy, dx]
+    return y
+
+
+def _layer(a, k, s1, t1, sc, s2, t2, dtype):
+    z = _direct(a.astype(dtype), k, dtype) * s1.astype(dtype) + t1.astype(dtype)
+    v = 1.0 / (1.0 + np.exp(-z))
+    if sc is not None:
+        v = (v + sc.astype(dtype)) * s2.astype(dtype) + t2.astype(dtype)
+    return v
+
+
+@pytest.mark.parametrize('B,H,W,residual', [(3, 20, 516, True), (2, 20, 258, False), (9, 5, 40, True), (1, 20, 561, False)])
+def test_fftconv_layer_vs_numpy(B, H, W, residual):
+    import torch
+    from amt_saga import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 1000 + W)
+    a = rng.random((B, H, W, 32)).astype(np.float32)                     # sigmoid-range activations
+    a[0] *= np.float32(3.0)                                              # windows of different scale: per-window operand scaling
+    k = (rng.standard_normal((4, 16, 32, 32)) * 0.05).astype(np.float32)
+    s1 = rng.uniform(0.5, 2.0, 32).astype(np.float32); t1 = rng.uniform(-1, 1, 32).astype(np.float32)
+    s2 = rng.uniform(0.5, 2.0, 32).astype(np.float32); t2 = rng.uniform(-1, 1, 32).astype(np.float32)
+    sc = rng.random((B, H, W, 32)).astype(np.float32) if residual else None
+    ref64 = _layer(a, k, s1, t1, sc, s2, t2, np.float64)
+    ref32 = _layer(a, k, s1, t1, sc, s2, t2, np.float32)
+    h = C.c_void_p()
+    fp = lambda x: x.ctypes.data_as(C.c_void_p)
+    _lib.check(lib.amt_fftconv_create(C.byref(h), fp(k), fp(s1), fp(t1), fp(s2) if residual else None, fp(t2) if residual else None))
+    try:
+        ad = torch.from_numpy(a).cuda()
+        scd = torch.from_numpy(sc).cuda() if residual else None
+        out = torch.empty_like(ad)
+        need = lib.amt_fftconv_workspace_bytes(B, H)
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device='cuda')
+        _lib.check(lib.amt_fftconv_run(h, ad.data_ptr(), scd.data_ptr() if residual else None, B, H, W, out.data_ptr(),
+                                       ws.data_ptr(), need, 1, None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    finally:
+        lib.amt_fftconv_destroy(h)
+    scale = np.abs(ref64).max()
+    e_gpu = np.abs(got - ref64).max() / scale
+    e_cpu = np.abs(ref32 - ref64).max() / scale
+    print('fftconv %dx%dx%d residual=%s: e_gpu %.3g  e_cpu(f32 direct) %.3g' % (B, H, W, residual, e_gpu, e_cpu))
+    assert e_gpu < 1e-5, e_gpu
+    assert e_gpu <= 2.5 * e_cpu + 2.4e-7, (e_gpu, e_cpu)
