@@ -18,7 +18,9 @@
 //     forward transform run in the same kernel: between two such layers the activations never exist in HBM in the
 //     spatial domain unless a later shortcut reads them.
 //
-// Frequency tensors: Xf / Yf [fp = 0 .. 288][b][h][64] f32, the 64 = side (f | 576 - f) x pair (16) x (re, im).
+// Frequency tensors: Xf / Yf [b][fp = 0 .. 288][h][64] f32, the 64 = side (f | 576 - f) x pair (16) x (re, im): a GEMM
+// workgroup reads H x 256 contiguous bytes per (window, fp), a row transform 256-byte pieces H x 256 bytes apart inside
+// its window's 1.5 MB (the first layout, [fp][b][h][64], put every piece of a row 5 MB from the next: 1.8 TB/s).
 #include "amt_fft.h"
 #include "amt_fftconv.h"
 #include <cmath>
@@ -89,6 +91,14 @@ struct FcRowArgs {
 };
 
 __device__ __forceinline__ float fc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// uniform base + unsigned 32-bit byte offset: the access takes its base from scalar registers and ONE address VGPR (as
+// 64-bit per-lane pointers the 72 addresses of a row thread alone overflowed the register file)
+template <typename T> __device__ __forceinline__ const T &fc_at(const void *base, unsigned int off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(base) + off);
+}
+template <typename T> __device__ __forceinline__ T &fc_at(void *base, unsigned int off) {
+    return *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(base) + off);
+}
 
 // One workgroup per image row (b, h).  IN_FREQ: inverse transform of Yf + epilogue; else the spatial input is loaded.
 // Then (a.Xf) the forward transform.
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            x[k2] = *reinterpret_cast<const float2 *>(a.Yf + (((size_t)fp * a.B + b) * a.H + h) * 64 + side * 32 + 2 * c16);
+            x[k2] = fc_at<float2>(a.Yf + ((size_t)b * FC_NP * a.H + h) * 64, (unsigned)((fp * a.H * 64 + side * 32 + 2 * c16) * 4));
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
@@ -126,6 +136,20 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
 #pragma unroll
         for (int k = 0; k < 24; ++k) x[k] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (n2 * 24 + k) * 2);
         fc_fft24<true>(x);
+        // the shortcut values this thread will add in the epilogue (positions w = 24 n1 + j24, channels 2 c16, 2 c16 + 1)
+        // are requested together and unconditionally (clamped address) in front of the epilogue: one exposed round trip
+        // per workgroup instead of 24 in a row (requested before the transforms they would not fit the register file)
+        float2 scv[24];
+        __builtin_amdgcn_sched_barrier(0);               // keep the requests behind the transforms (register file)
+        if (a.sc) {
+            const float *sp_ = a.sc + (size_t)b * a.sc_stride + (size_t)h * a.W * 32;
+#pragma unroll
+            for (int n1 = 0; n1 < 24; ++n1) scv[n1] = fc_at<float2>(sp_, (unsigned)((min(24 * n1 + j24, a.W - 1) * 32 + 2 * c16) * 4));
+        } else if (a.sc1) {
+            const float *sp_ = a.sc1 + (size_t)b * a.sc1_stride + (size_t)h * a.W;
+#pragma unroll
+            for (int n1 = 0; n1 < 24; ++n1) scv[n1].x = fc_at<float>(sp_, (unsigned)(min(24 * n1 + j24, a.W - 1) * 4));
+        }
         // ---- epilogue: channels 2 c16 (real part) and 2 c16 + 1 (imaginary part), positions w = 24 n1 + n2
         const int c0 = 2 * c16;
         const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
@@ -147,17 +171,16 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
                 v.x = fc_sigmoid((x[n1].x * inv_n) * s1a + t1a);
                 v.y = fc_sigmoid((x[n1].y * inv_n) * s1b + t1b);
                 if (a.sc) {
-                    const float2 s = *reinterpret_cast<const float2 *>(a.sc + (size_t)b * a.sc_stride + ((size_t)h * a.W + w) * 32 + c0);
+                    const float2 s = scv[n1];
                     v.x = (v.x + s.x) * s2a + t2a;
                     v.y = (v.y + s.y) * s2b + t2b;
                 } else if (a.sc1) {
-                    const float xi = a.sc1[(size_t)b * a.sc1_stride + (size_t)h * a.W + w];
+                    const float xi = scv[n1].x;
                     v.x = (v.x + (fmaf(xi, pw0, 0.f) * ps0 + pt0)) * s2a + t2a;
                     v.y = (v.y + (fmaf(xi, pw1, 0.f) * ps1 + pt1)) * s2b + t2b;
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-                if (a.out_sp)
-                    *reinterpret_cast<float2 *>(a.out_sp + (size_t)b * a.out_stride + ((size_t)h * a.W + w) * 32 + c0) = v;
+                if (a.out_sp) fc_at<float2>(a.out_sp + (size_t)b * a.out_stride + (size_t)h * a.W * 32, (unsigned)((w * 32 + c0) * 4)) = v;
             }
             x[n1] = v;
         }
@@ -168,13 +191,18 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
         if (!a.Xf) return;
         __syncthreads();                                    // every thread has read its column of `buf`
     } else {
+        // branch-free: the load goes to a clamped address and a select zeroes the padding (a conditional load is a branch,
+        // and 24 branches are 24 serialised round trips to memory)
         const int n2 = j24;
+        const float *rowp = a.in_sp + (size_t)b * a.in_stride + (size_t)h * a.W * 32;
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) {
             const int w = 24 * n1 + n2;
-            x[n1] = w < a.W ? *reinterpret_cast<const float2 *>(a.in_sp + (size_t)b * a.in_stride + ((size_t)h * a.W + w) * 32 + 2 * c16)
-                            : make_float2(0.f, 0.f);
+            x[n1] = fc_at<float2>(rowp, (unsigned)((min(w, a.W - 1) * 32 + 2 * c16) * 4));
         }
+#pragma unroll
+        for (int n1 = 0; n1 < 24; ++n1)
+            if (24 * n1 + n2 >= a.W) x[n1] = make_float2(0.f, 0.f);
         __syncthreads();                                    // the twiddle table is in place
     }
     // ---- forward: thread (p = c16, n2 = j24) transforms over n1 -> k1, twiddles, transposition, (p, k1 = j24) over n2 -> k2
@@ -196,9 +224,10 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            float *dst = a.Xf + (((size_t)fp * a.B + b) * a.H + h) * 64 + 2 * c16;
-            *reinterpret_cast<float2 *>(dst + side * 32) = x[k2];
-            if (f == 0 || f == FC_NF / 2) *reinterpret_cast<float2 *>(dst + 32) = x[k2];     // self-paired bins fill both sides
+            float *xb = a.Xf + ((size_t)b * FC_NP * a.H + h) * 64;
+            const unsigned int off = (unsigned)((fp * a.H * 64 + 2 * c16) * 4);
+            fc_at<float2>(xb, off + side * 128) = x[k2];
+            if (f == 0 || f == FC_NF / 2) fc_at<float2>(xb, off + 128) = x[k2];          // self-paired bins fill both sides
             fmax_ = fmaxf(fmax_, fmaxf(fabsf(x[k2].x), fabsf(x[k2].y)));
         }
         fmax_ = wave_max(fmax_);
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     float *sa_s = reinterpret_cast<float *>(al + (size_t)rows_cap * FC_APITCH);      // [FC_CW] 2^sa, then [FC_CW] 2^-(sa + sw)
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int wm = wid >> 1, wn = wid & 1;
-    const int fp = blockIdx.y;
+    const int fp = blockIdx.x;                     // fastest: concurrently running workgroups read neighbouring 5 KB blocks
     const int H = a.H;
     // weight fragments of this wave's two N-tiles, all eight k-steps, both planes
     fc_h8 bh[8][2], bl[8][2];
@@ -256,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     const int sw = a.gsw[fp];
     const int nchunks = (a.B + FC_CW - 1) / FC_CW;
     for (int it = 0; it < a.nchunk_per_wg; ++it) {
-        const int chunk = blockIdx.x * a.nchunk_per_wg + it;
+        const int chunk = blockIdx.y * a.nchunk_per_wg + it;
         if (chunk >= nchunks) break;                        // uniform
         const int b0 = chunk * FC_CW;
         const int nw = min(FC_CW, a.B - b0);
@@ -268,16 +297,30 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
             sa_s[FC_CW + tid] = ldexpf(1.0f, -(s_ + sw));
         }
         __syncthreads();
-        // stage: 16 float4 per row
-        const float *src = a.Xf + ((size_t)fp * a.B + b0) * H * 64;
-        for (int i = tid; i < rows * 16; i += 256) {
-            const int row = i >> 4, c4 = i & 15;
-            const fc_f4 v = *reinterpret_cast<const fc_f4 *>(src + (size_t)row * 64 + 4 * c4) * sa_s[row / H];
-            const fc_h4 hh = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            const fc_h4 ll = {(_Float16)((v.x - (float)hh.x) * FC_LSCALE), (_Float16)((v.y - (float)hh.y) * FC_LSCALE),
-                              (_Float16)((v.z - (float)hh.z) * FC_LSCALE), (_Float16)((v.w - (float)hh.w) * FC_LSCALE)};
-            *reinterpret_cast<fc_h4 *>(ah + (size_t)row * FC_APITCH + 4 * c4) = hh;
-            *reinterpret_cast<fc_h4 *>(al + (size_t)row * FC_APITCH + 4 * c4) = ll;
+        // stage: 16 float4 per row; row r = (window r / H, image row r % H).  All of a thread's loads are issued before
+        // the first conversion (inside one loop every load was waited for in turn: ten round trips per chunk)
+        constexpr int NLD = (FC_CW * 20 * 16 + 255) / 256;              // loads per thread at H = 20 (more rows: second pass)
+        for (int base = 0; base < rows * 16; base += NLD * 256) {
+            fc_f4 pre[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i = min(base + tid + 256 * u, rows * 16 - 1);
+                const int row = i >> 4, c4 = i & 15;
+                const int wi = row / H, hr = row - wi * H;
+                pre[u] = *reinterpret_cast<const fc_f4 *>(a.Xf + (((size_t)(b0 + wi) * FC_NP + fp) * H + hr) * 64 + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i = base + tid + 256 * u;
+                if (i >= rows * 16) continue;
+                const int row = i >> 4, c4 = i & 15;
+                const fc_f4 v = pre[u] * sa_s[row / H];
+                const fc_h4 hh = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                const fc_h4 ll = {(_Float16)((v.x - (float)hh.x) * FC_LSCALE), (_Float16)((v.y - (float)hh.y) * FC_LSCALE),
+                                  (_Float16)((v.z - (float)hh.z) * FC_LSCALE), (_Float16)((v.w - (float)hh.w) * FC_LSCALE)};
+                *reinterpret_cast<fc_h4 *>(ah + (size_t)row * FC_APITCH + 4 * c4) = hh;
+                *reinterpret_cast<fc_h4 *>(al + (size_t)row * FC_APITCH + 4 * c4) = ll;
+            }
         }
         __syncthreads();
         const int n_mt = (rows + 15) >> 4;
@@ -310,14 +353,16 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
                 }
             }
             // D: column n = lane & 15, rows 4 (lane >> 4) + e
-            float *dst = a.Yf + ((size_t)fp * a.B + b0) * H * 64;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int n = 16 * (2 * wn + nt) + (lane & 15);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ro = 16 * mt + 4 * (lane >> 4) + e;
-                    if (ro < rows) dst[(size_t)ro * 64 + n] = (hi[nt][e] + lo[nt][e] * (1.0f / FC_LSCALE)) * sa_s[FC_CW + ro / H];
+                    const int wi = ro / H, hr = ro - wi * H;
+                    if (ro < rows)
+                        a.Yf[(((size_t)(b0 + wi) * FC_NP + fp) * H + hr) * 64 + n] =
+                            (hi[nt][e] + lo[nt][e] * (1.0f / FC_LSCALE)) * sa_s[FC_CW + wi];
                 }
             }
         }
@@ -468,7 +513,7 @@ int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *a
     int per = 1;
     while ((size_t)((nchunks + per - 1) / per) * FC_NP > 4096 && per < 16) per *= 2;      // ~2 resident rounds of workgroups
     FcGemmArgs a{Xf, Yf, amaxf, L->gw, L->gsw, B, H, per};
-    fc_gemm_kernel<<<dim3((nchunks + per - 1) / per, FC_NP), 256, lds, st>>>(a);
+    fc_gemm_kernel<<<dim3(FC_NP, (nchunks + per - 1) / per), 256, lds, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

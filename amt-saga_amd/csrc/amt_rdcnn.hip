@@ -27,6 +27,7 @@
 //   * epilogue: acc*s1+t1 -> sigmoid -> (+shortcut)*s2+t2 -> coalesced NHWC
 //     stores (a store instruction = two full 128-B channel rows).
 #include "amt_common.h"
+#include "amt_fftconv.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -935,6 +936,10 @@ struct ConvOp {
     bool maskedh = false;
     double effh = 0;
     int sw = 0;                // weights scaled by 2^sw
+    // FFT-domain form (conv mode 3, amt_fftconv.hip): built on the first amt_rdcnn_set_mode(net, 3) for the
+    // 32 -> 32 (4 x 16) layers on images of at most 561 columns; k_host keeps the Keras-layout kernel for that
+    std::vector<float> k_host;
+    amt_fftconv_layer *fft = nullptr;
 };
 struct ProjOp {
     int cin, cout, H, W, ph, pw, HO, WO;
@@ -1296,6 +1301,9 @@ int amt_rdcnn_destroy(amt_rdcnn *net) {
     for (const ProfPending &pp : net->prof_pending) { (void)hipEventDestroy(pp.e0); (void)hipEventDestroy(pp.e1); }
     for (hipEvent_t e : net->prof_free) (void)hipEventDestroy(e);
     for (float *p : net->allocs) (void)hipFree(p);
+    for (Tower &t : net->towers)
+        for (ConvOp &c : t.convs)
+            if (c.fft) amt_fftconv_layer_destroy_internal(c.fft);
     delete net;
     return AMT_OK;
 }
@@ -1344,6 +1352,8 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     amt_rdcnn_destroy(n);
                     return AMT_E_UNSUPPORTED;
                 }
+                if (kh == 4 && kw == 16 && C == 32 && fo == 32 && W + 15 <= 576)
+                    c.k_host.assign(kern, kern + (size_t)kh * kw * C * fo);      // FFT-domain form, built on demand (mode 3)
                 const int NT = fo / 32, nch = C / 32, ntap = kh * kw;
                 // small late-stage layers (few output positions per window) cannot fill 256 CUs with
                 // position tiles alone: compute them in 32-channel output slices (blockIdx.y)
@@ -1512,7 +1522,17 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
 double amt_rdcnn_flops_per_window(const amt_rdcnn *net) { return net ? net->flops : 0.0; }
 
 int amt_rdcnn_set_mode(amt_rdcnn *net, int mode) {
-    if (!net || mode < 0 || mode > 2) return AMT_E_INVALID;
+    if (!net || mode < 0 || mode > 3) return AMT_E_INVALID;
+    if (mode == 3) {
+        // FFT-domain form of the 32 -> 32 (4 x 16) layers (every other layer runs the split-fp16 kernels of mode 2):
+        // the transformed kernel matrices are computed on the host in float64, once
+        for (Tower &t : net->towers)
+            for (ConvOp &c : t.convs)
+                if (!c.fft && !c.k_host.empty()) {
+                    const int rc = amt_fftconv_layer_create_internal(&c.fft, c.k_host.data());
+                    if (rc != AMT_OK) return rc;
+                }
+    }
     net->mode = mode;
     return AMT_OK;
 }
@@ -1566,8 +1586,13 @@ static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);
     ma = (ma + 3) & ~(size_t)3;
     // + per-window max |activation| of the network input and of every conv layer's output (split-fp16 scaling)
+    size_t fft = 0;                                      // mode 3: two frequency tensors + per-window max |Xf|
+    if (n->mode == 3)
+        for (const Tower &t : n->towers)
+            for (const ConvOp &c : t.convs)
+                if (c.fft) fft = std::max(fft, 2 * amt_fftconv_freq_floats(Bc, c.H) + (size_t)Bc + 8);
     return (size_t)Bc * (4 * ma + (size_t)((n->flat + 3) & ~3) + (size_t)((n->d.dense_units + 3) & ~3) +
-                         (size_t)((n->d.output_classes + 3) & ~3) + (size_t)(n->d.conv_layers + 1)) + 8;
+                         (size_t)((n->d.output_classes + 3) & ~3) + (size_t)(n->d.conv_layers + 1)) + 8 + fft;
 }
 
 size_t amt_rdcnn_workspace_bytes(const amt_rdcnn *net, int B) {
@@ -1605,7 +1630,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
         for (int t = 0; t < d.n_towers; ++t) {
             const Tower &tw = net->towers[t];
             const float *cur = x[t] + (size_t)b0 * tw.in_h * tw.in_w;
-            if (net->mode == 2) {
+            if (net->mode >= 2) {
                 AMT_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)(d.conv_layers + 1) * Bc * sizeof(float), st));
                 const size_t nin = (size_t)tw.in_h * tw.in_w;
                 absmax_kernel<<<dim3((unsigned)std::min<size_t>((nin + 1023) / 1024, 64), Bc), 256, 0, st>>>(cur, nin, nin, amax);
@@ -1614,6 +1639,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
             const float *p0 = cur; size_t p0_stride = cur_stride;
             int H = tw.in_h, W = tw.in_w;
             const int L = (int)tw.convs.size();
+            bool xf_valid = false;                       // mode 3: the previous layer left its output transformed in Xf
             auto pick = [&](const float *a, const float *b_, const float *c_) -> float * {
                 for (int i = 0; i < 4; ++i)
                     if (buf[i] != a && buf[i] != b_ && buf[i] != c_) return buf[i];
@@ -1627,7 +1653,8 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                 const float *sc = nullptr; size_t sc_stride = 0;
                 const ProjOp *rank1 = nullptr;
                 if (c.residual) {
-                    if (c.sc_proj >= 0 && net->mode == 2 && c.whs && !c.maskedh && tw.projs[c.sc_proj].cin == 1 &&
+                    if (c.sc_proj >= 0 && ((net->mode == 2 && c.whs && !c.maskedh) || (net->mode == 3 && (c.fft || (c.whs && !c.maskedh)))) &&
+                        tw.projs[c.sc_proj].cin == 1 &&
                         tw.projs[c.sc_proj].ph == 1 && tw.projs[c.sc_proj].pw == 1 && tw.projs[c.sc_proj].w) {
                         rank1 = &tw.projs[c.sc_proj];                 // formed in the consumer's epilogue
                     } else if (c.sc_proj >= 0) {
@@ -1651,7 +1678,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     AMT_HIP_CHECK(hipEventRecord(pe0, st));
                 }
                 // split-fp16 scaling: layer i reads amax[i] (its input) and leaves amax[i + 1] (its output)
-                float *amax_o = net->mode == 2 ? amax + (size_t)(i + 1) * Bc : nullptr;
+                float *amax_o = net->mode >= 2 ? amax + (size_t)(i + 1) * Bc : nullptr;
                 bool wrote_amax = false;
                 if (c.cin == 1 && c.cout == 32 && conv_supported(c.kh, c.kw)) {
                     Conv1Params cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
@@ -1678,6 +1705,33 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                     const size_t tiles = (size_t)Bc * H * ((W + groups * C1_PPT - 1) / (groups * C1_PPT));
                     conv1_kernel<<<(unsigned)std::min<size_t>(tiles, 8192), 256, lds, st>>>(cp);
                     AMT_LAUNCH_CHECK();
+                } else if (net->mode == 3 && c.fft) {
+                    // FFT-domain form: [forward transform of the spatial input, unless the previous layer left its
+                    // output transformed] -> per-frequency GEMM -> inverse + epilogue [+ forward transform for the next
+                    // such layer]; the spatial output is written only where something reads it (a later shortcut, a
+                    // pooling, a layer of another kind)
+                    float *Xf = amax + (size_t)(d.conv_layers + 1) * Bc + 8;
+                    Xf = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(Xf) + 15) & ~(uintptr_t)15);
+                    float *Yf = Xf + amt_fftconv_freq_floats(Bc, H);
+                    float *amaxf = Yf + amt_fftconv_freq_floats(Bc, H);
+                    int rc = AMT_OK;
+                    if (!xf_valid) rc = amt_fftconv_forward_fft(c.fft, cur, cur_stride, Bc, H, W, Xf, amaxf, st);
+                    if (rc == AMT_OK) rc = amt_fftconv_gemm(c.fft, Xf, amaxf, Bc, H, Yf, st);
+                    if (rc != AMT_OK) return rc;
+                    const bool next_fft = i + 1 < L && !c.pool_after && tw.convs[i + 1].fft;
+                    const bool need_sp = !next_fft || c.residual;
+                    FcEpilogue ep;
+                    ep.s1 = c.s1; ep.t1 = c.t1;
+                    if (c.residual) {
+                        ep.s2 = c.s2; ep.t2 = c.t2;
+                        if (rank1) { ep.sc1 = p0; ep.sc1_stride = p0_stride; ep.sc1_w = rank1->w; ep.sc1_s = rank1->s; ep.sc1_t = rank1->t; }
+                        else { ep.sc = sc; ep.sc_stride = sc_stride; }
+                    }
+                    rc = amt_fftconv_inverse_epilogue(c.fft, Yf, ep, Bc, H, W, need_sp ? o : nullptr, o_stride,
+                                                      next_fft ? Xf : nullptr, amaxf, amax_o, st);
+                    if (rc != AMT_OK) return rc;
+                    xf_valid = next_fft;
+                    wrote_amax = true;
                 } else {
                     ConvParams cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,
                                   c.residual ? c.s2 : nullptr, c.residual ? c.t2 : nullptr,
@@ -1687,7 +1741,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         cp.sc1 = p0; cp.sc1_win_stride = p0_stride;
                         cp.sc1_w = rank1->w; cp.sc1_s = rank1->s; cp.sc1_t = rank1->t;
                     }
-                    const bool fp16 = net->mode == 2 && c.whs;
+                    const bool fp16 = net->mode >= 2 && c.whs;
                     const int rc = fp16 ? launch_convh(c, cp, amax + (size_t)i * Bc, amax_o, st)
                                    : (net->mode >= 1 && c.w16) ? launch_conv16(c, cp, st) : launch_conv(c, cp, st);
                     if (rc != AMT_OK) return rc;

@@ -44,7 +44,8 @@ def _inputs(shape, B, seed):
 
 
 def _check_head(env, head, cfg, B, seed, modes=(0, 1, 2), name=None, xs=None):
-    """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16) against the oracle (computed once)."""
+    """All convolution arithmetics (f32 MFMA, split-bf16, split-fp16; 3 = FFT-domain form where asked) against the
+    oracle (computed once)."""
     if xs is None:
         xs = [_inputs(s[:2], B, seed + t) for t, s in enumerate(cfg['input_shapes'])]
     xo = [x[..., None] for x in xs]
@@ -131,7 +132,7 @@ def test_timing_head_n4096(env):
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
     assert cfg['input_shapes'][0] == (20, 258, 1)
-    _check_head(env, h, cfg, 6, 5, name='timing N=4096')
+    _check_head(env, h, cfg, 6, 5, name='timing N=4096', modes=(0, 1, 2, 3))
 
 
 def test_timing_head_n2048_batch_independent(env):
@@ -141,7 +142,7 @@ def test_timing_head_n2048_batch_independent(env):
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].timming_classifier(p)
     cfg = env['orc'].head_config(p, 'timing')
-    _check_head(env, h, cfg, 8, 6, name='timing N=2048')
+    _check_head(env, h, cfg, 8, 6, name='timing N=2048', modes=(0, 1, 2, 3))
     torch = env['torch']
     x = torch.from_numpy(_inputs((20, 516), 13, 7)).cuda()
     y = h.predict_device([x]).cpu().numpy()
@@ -150,8 +151,8 @@ def test_timing_head_n2048_batch_independent(env):
     assert np.array_equal(y[perm], y2)
     y3 = h.predict_device([x[:1].contiguous()]).cpu().numpy()
     assert np.array_equal(y[:1], y3)
-    # split-bf16 / split-fp16 convolutions: same properties, and within 1e-4 of the f32-MFMA result
-    for mode in (1, 2):
+    # split-bf16 / split-fp16 / FFT-domain convolutions: same properties, and within 1e-4 of the f32-MFMA result
+    for mode in (1, 2, 3):
         h.set_mode(mode)
         z = h.predict_device([x]).cpu().numpy()
         z2 = h.predict_device([x[torch.from_numpy(perm).cuda()].contiguous()]).cpu().numpy()
@@ -492,7 +493,9 @@ def test_small_topologies(env, case):
                                feature_expand_frequency=case['ef'],
                                pool_layer_frequency=case['pf'],
                                residual_layer_frequencies=case['r'], weight_seed=77)
-    _check_head(env, net, net.cfg, 6, 11, name='shallow %s k%s' % (case['shape'], case['k']))
+    # (mode 3 = the FFT-domain form, built for the 32 -> 32 layers with 4 x 16 kernels; other layers run mode 2's kernels)
+    _check_head(env, net, net.cfg, 6, 11, name='shallow %s k%s' % (case['shape'], case['k']),
+                modes=(0, 1, 2, 3) if case['k'] == (4, 16) else (0, 1, 2))
 
 
 @pytest.mark.parametrize('hop,L,grids', [
