@@ -23,6 +23,7 @@
 // its window's 1.5 MB (the first layout, [fp][b][h][64], put every piece of a row 5 MB from the next: 1.8 TB/s).
 #include "amt_fft.h"
 #include "amt_fftconv.h"
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -102,25 +103,32 @@ template <typename T> __device__ __forceinline__ T &fc_at(void *base, unsigned i
 
 // One workgroup per image row (b, h).  IN_FREQ: inverse transform of Yf + epilogue; else the spatial input is loaded.
 // Then (a.Xf) the forward transform.
+// Two image rows per 768-thread workgroup, each half (384 threads, six waves) with its own transposition buffer: the
+// kernel is bound by memory latency and needs two rows in flight per CU, but two SEPARATE 6-wave workgroups of 168
+// registers do not fit a CU's SIMDs together (2 + 2 waves on one SIMD > 3) -- measured: one resident, 66 % of the wave
+// cycles waiting -- while twelve waves of ONE workgroup spread three per SIMD.
 template <bool IN_FREQ>
-__global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
+__global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fc_smem[];
-    float *buf = fc_smem;                                   // [16][FC_PS]
-    float2 *tw = reinterpret_cast<float2 *>(fc_smem + 16 * FC_PS);
-    const int tid = threadIdx.x;
+    const int half = threadIdx.x >= FC_THREADS ? 1 : 0;
+    const int tid = threadIdx.x - half * FC_THREADS;
+    float *buf = fc_smem + (size_t)half * 16 * FC_PS;       // [16][FC_PS] per half
+    float2 *tw = reinterpret_cast<float2 *>(fc_smem + 2 * 16 * FC_PS);
     const int c16 = (tid >> 2) & 15;                        // channel pair
     const int j24 = (tid & 3) + 4 * (tid >> 6);             // 0 .. 23
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    for (int i = tid; i < FC_NF; i += FC_THREADS) tw[i] = a.tw[i];
+    const int row = min(2 * (int)blockIdx.x + half, a.B * a.H - 1);     // (an odd row count: the last row is done twice)
+    const int b = row / a.H, h = row - b * a.H;
+    for (int i = threadIdx.x; i < FC_NF; i += 2 * FC_THREADS) tw[i] = a.tw[i];
     float2 x[24];
     if (IN_FREQ) {
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
         const int k1 = j24;
+        const float *yb = a.Yf + ((size_t)b * FC_NP * a.H + h) * 64;
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            x[k2] = fc_at<float2>(a.Yf + ((size_t)b * FC_NP * a.H + h) * 64, (unsigned)((fp * a.H * 64 + side * 32 + 2 * c16) * 4));
+            x[k2] = fc_at<float2>(yb, (unsigned)((fp * a.H * 64 + side * 32 + 2 * c16) * 4));
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
@@ -136,60 +144,77 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
 #pragma unroll
         for (int k = 0; k < 24; ++k) x[k] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (n2 * 24 + k) * 2);
         fc_fft24<true>(x);
-        // the shortcut values this thread will add in the epilogue (positions w = 24 n1 + j24, channels 2 c16, 2 c16 + 1)
-        // are requested together and unconditionally (clamped address) in front of the epilogue: one exposed round trip
-        // per workgroup instead of 24 in a row (requested before the transforms they would not fit the register file)
-        float2 scv[24];
-        __builtin_amdgcn_sched_barrier(0);               // keep the requests behind the transforms (register file)
-        if (a.sc) {
-            const float *sp_ = a.sc + (size_t)b * a.sc_stride + (size_t)h * a.W * 32;
-#pragma unroll
-            for (int n1 = 0; n1 < 24; ++n1) scv[n1] = fc_at<float2>(sp_, (unsigned)((min(24 * n1 + j24, a.W - 1) * 32 + 2 * c16) * 4));
-        } else if (a.sc1) {
-            const float *sp_ = a.sc1 + (size_t)b * a.sc1_stride + (size_t)h * a.W;
-#pragma unroll
-            for (int n1 = 0; n1 < 24; ++n1) scv[n1].x = fc_at<float>(sp_, (unsigned)(min(24 * n1 + j24, a.W - 1) * 4));
-        }
-        // ---- epilogue: channels 2 c16 (real part) and 2 c16 + 1 (imaginary part), positions w = 24 n1 + n2
-        const int c0 = 2 * c16;
-        const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
-        const bool res = a.s2 != nullptr;
-        const float s2a = res ? a.s2[c0] : 1.f, s2b = res ? a.s2[c0 + 1] : 1.f;
-        const float t2a = res ? a.t2[c0] : 0.f, t2b = res ? a.t2[c0 + 1] : 0.f;
-        float pw0 = 0.f, pw1 = 0.f, ps0 = 0.f, ps1 = 0.f, pt0 = 0.f, pt1 = 0.f;
-        if (a.sc1) {
-            pw0 = a.sc1_w[c0]; pw1 = a.sc1_w[c0 + 1]; ps0 = a.sc1_s[c0]; ps1 = a.sc1_s[c0 + 1];
-            pt0 = a.sc1_t[c0]; pt1 = a.sc1_t[c0 + 1];
-        }
+        __syncthreads();                                    // every thread has read its column: `buf` becomes [w][pair]
+        // ---- epilogue through LDS: the transform leaves 24 positions x 2 channels per thread in registers; adding 24
+        // shortcut values to them there costs 48 more live registers and a second workgroup per CU (the kernel is bound
+        // by memory latency: it needs two).  Instead the row goes to LDS position-major and a compact loop -- thread i:
+        // position i / 16, pair i % 16, 64-bit coalesced shortcut loads and output stores -- applies BN + sigmoid
+        // (+ shortcut + BN) in place.
+        float2 *ybuf = reinterpret_cast<float2 *>(buf);     // [576][16] complex = (channel 2 q, channel 2 q + 1)
         const float inv_n = 1.0f / (float)FC_NF;
-        float vmax = 0.f;
 #pragma unroll
-        for (int n1 = 0; n1 < 24; ++n1) {
-            const int w = 24 * n1 + n2;
-            float2 v = make_float2(0.f, 0.f);
-            if (w < a.W) {
-                v.x = fc_sigmoid((x[n1].x * inv_n) * s1a + t1a);
-                v.y = fc_sigmoid((x[n1].y * inv_n) * s1b + t1b);
-                if (a.sc) {
-                    const float2 s = scv[n1];
-                    v.x = (v.x + s.x) * s2a + t2a;
-                    v.y = (v.y + s.y) * s2b + t2b;
-                } else if (a.sc1) {
-                    const float xi = scv[n1].x;
+        for (int n1 = 0; n1 < 24; ++n1) ybuf[(24 * n1 + n2) * 16 + c16] = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
+        __syncthreads();
+        {
+            const int q = tid & 15, c0 = 2 * q;
+            const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+            const bool res = a.s2 != nullptr;
+            const float s2a = res ? a.s2[c0] : 1.f, s2b = res ? a.s2[c0 + 1] : 1.f;
+            const float t2a = res ? a.t2[c0] : 0.f, t2b = res ? a.t2[c0 + 1] : 0.f;
+            float pw0 = 0.f, pw1 = 0.f, ps0 = 0.f, ps1 = 0.f, pt0 = 0.f, pt1 = 0.f;
+            if (a.sc1) {
+                pw0 = a.sc1_w[c0]; pw1 = a.sc1_w[c0 + 1]; ps0 = a.sc1_s[c0]; ps1 = a.sc1_s[c0 + 1];
+                pt0 = a.sc1_t[c0]; pt1 = a.sc1_t[c0 + 1];
+            }
+            const float *scb = a.sc ? a.sc + (size_t)b * a.sc_stride + (size_t)h * a.W * 32 : nullptr;
+            const float *sc1b = a.sc1 ? a.sc1 + (size_t)b * a.sc1_stride + (size_t)h * a.W : nullptr;
+            float *ob = a.out_sp ? a.out_sp + (size_t)b * a.out_stride + (size_t)h * a.W * 32 : nullptr;
+            float vmax = 0.f;
+            const int n_el = a.W * 16;                      // (FC_THREADS is a multiple of 16: a thread keeps its pair)
+            constexpr int NIT = FC_NF * 16 / FC_THREADS;    // 24 elements per thread at most
+            // every shortcut value of the thread is requested before the first is used (clamped address, no branch): the
+            // row's registers are in LDS at this point, so the 24 values fit
+            float2 scv[NIT];
+            if (scb) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) scv[it] = fc_at<float2>(scb, (unsigned)(min(tid + FC_THREADS * it, n_el - 1) * 8));
+            } else if (sc1b) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) scv[it].x = fc_at<float>(sc1b, (unsigned)((min(tid + FC_THREADS * it, n_el - 1) >> 4) * 4));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + FC_THREADS * it;
+                if (i >= n_el) break;
+                float2 v = ybuf[i];
+                v.x = fc_sigmoid(v.x * s1a + t1a);
+                v.y = fc_sigmoid(v.y * s1b + t1b);
+                if (scb) {
+                    v.x = (v.x + scv[it].x) * s2a + t2a;
+                    v.y = (v.y + scv[it].y) * s2b + t2b;
+                } else if (sc1b) {
+                    const float xi = scv[it].x;
                     v.x = (v.x + (fmaf(xi, pw0, 0.f) * ps0 + pt0)) * s2a + t2a;
                     v.y = (v.y + (fmaf(xi, pw1, 0.f) * ps1 + pt1)) * s2b + t2b;
                 }
                 vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-                if (a.out_sp) fc_at<float2>(a.out_sp + (size_t)b * a.out_stride + (size_t)h * a.W * 32, (unsigned)((w * 32 + c0) * 4)) = v;
+                if (ob) fc_at<float2>(ob, (unsigned)(i * 8)) = v;
+                ybuf[i] = v;
             }
-            x[n1] = v;
-        }
-        if (a.amax_out) {
-            vmax = wave_max(vmax);
-            if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
+            if (a.amax_out) {
+                vmax = wave_max(vmax);
+                if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
+            }
         }
         if (!a.Xf) return;
-        __syncthreads();                                    // every thread has read its column of `buf`
+        __syncthreads();
+#pragma unroll
+        for (int n1 = 0; n1 < 24; ++n1) {
+            const int w = 24 * n1 + n2;
+            x[n1] = ybuf[min(w, a.W - 1) * 16 + c16];
+            if (w >= a.W) x[n1] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();                                    // `buf` is free for the forward transposition
     } else {
         // branch-free: the load goes to a clamped address and a select zeroes the padding (a conditional load is a branch,
         // and 24 branches are 24 serialised round trips to memory)
@@ -220,11 +245,11 @@ __global__ __launch_bounds__(FC_THREADS) void fc_row_kernel(FcRowArgs a) {
         for (int n = 0; n < 24; ++n) x[n] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (k1 * 24 + n) * 2);
         fc_fft24<false>(x);
         float fmax_ = 0.f;
+        float *xb = a.Xf + ((size_t)b * FC_NP * a.H + h) * 64;
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            float *xb = a.Xf + ((size_t)b * FC_NP * a.H + h) * 64;
             const unsigned int off = (unsigned)((fp * a.H * 64 + 2 * c16) * 4);
             fc_at<float2>(xb, off + side * 128) = x[k2];
             if (f == 0 || f == FC_NF / 2) fc_at<float2>(xb, off + 128) = x[k2];          // self-paired bins fill both sides
@@ -259,16 +284,29 @@ __device__ __forceinline__ int fc_scale_exp(float amax) {
     return min(max(13 - e, -90), 90);
 }
 
+#define FC_OPITCH 36                    // floats per row of a wave's output transposition patch
+
 __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fcg_smem[];
-    _Float16 *ah = reinterpret_cast<_Float16 *>(fcg_smem);                   // [rows][FC_APITCH]
-    const int rows_cap = FC_CW * a.H;
-    _Float16 *al = ah + (size_t)rows_cap * FC_APITCH;
-    float *sa_s = reinterpret_cast<float *>(al + (size_t)rows_cap * FC_APITCH);      // [FC_CW] 2^sa, then [FC_CW] 2^-(sa + sw)
+    const int H = a.H;
+    const int rows_cap = FC_CW * H;
+    _Float16 *ah = reinterpret_cast<_Float16 *>(fcg_smem);                   // [rows_cap + 1][FC_APITCH]; the last row is zeros
+    _Float16 *al = ah + (size_t)(rows_cap + 1) * FC_APITCH;
+    float *patch = reinterpret_cast<float *>(al + (size_t)(rows_cap + 1) * FC_APITCH);       // [4 waves][16][FC_OPITCH]
+    float *sa_s = patch + 4 * 16 * FC_OPITCH;                                // [FC_CW] 2^sa, then [FC_CW] 2^-(sa + sw)
+    unsigned int *roff = reinterpret_cast<unsigned int *>(sa_s + 2 * FC_CW); // [rows_cap] byte offset of a chunk row in Xf / Yf
+    unsigned char *rwin = reinterpret_cast<unsigned char *>(roff + rows_cap);        // [rows_cap] window of the row
+    unsigned char *rh = rwin + rows_cap;                                             // [rows_cap] image row
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int wm = wid >> 1, wn = wid & 1;
     const int fp = blockIdx.x;                     // fastest: concurrently running workgroups read neighbouring 5 KB blocks
-    const int H = a.H;
+    // row tables (the same for every chunk) and the zero row the out-of-image taps read
+    for (int r = tid; r < rows_cap; r += 256) {
+        const int wi = r / H, hr = r - wi * H;
+        roff[r] = (unsigned int)(((size_t)wi * FC_NP * H + hr) * 64 * 4);
+        rwin[r] = (unsigned char)wi; rh[r] = (unsigned char)hr;
+    }
+    if (tid < FC_APITCH) { ah[(size_t)rows_cap * FC_APITCH + tid] = (_Float16)0.f; al[(size_t)rows_cap * FC_APITCH + tid] = (_Float16)0.f; }
     // weight fragments of this wave's two N-tiles, all eight k-steps, both planes
     fc_h8 bh[8][2], bl[8][2];
     {
@@ -284,8 +322,22 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     }
     const int sw = a.gsw[fp];
     const int nchunks = (a.B + FC_CW - 1) / FC_CW;
-    for (int it = 0; it < a.nchunk_per_wg; ++it) {
-        const int chunk = blockIdx.y * a.nchunk_per_wg + it;
+    constexpr int NLD = (FC_CW * 20 * 16 + 255) / 256;      // staged float4 per thread (H <= 20; the host refuses taller images)
+    fc_f4 pre[NLD];
+    __syncthreads();                                        // the row tables are in place
+    auto fetch = [&](int chunk) {                           // a chunk's activations -> registers (clamped addresses, no branch)
+        const int b0 = chunk * FC_CW;
+        const int rows = min(FC_CW, a.B - b0) * H;
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(a.Xf + ((size_t)b0 * FC_NP + fp) * H * 64);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = min(tid + 256 * u, rows * 16 - 1);
+            pre[u] = fc_at<fc_f4>(base, roff[i >> 4] + (unsigned)((i & 15) * 16));
+        }
+    };
+    int chunk = blockIdx.y * a.nchunk_per_wg;
+    if (chunk < nchunks) fetch(chunk);
+    for (int it = 0; it < a.nchunk_per_wg; ++it, ++chunk) {
         if (chunk >= nchunks) break;                        // uniform
         const int b0 = chunk * FC_CW;
         const int nw = min(FC_CW, a.B - b0);
@@ -297,53 +349,41 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
             sa_s[FC_CW + tid] = ldexpf(1.0f, -(s_ + sw));
         }
         __syncthreads();
-        // stage: 16 float4 per row; row r = (window r / H, image row r % H).  All of a thread's loads are issued before
-        // the first conversion (inside one loop every load was waited for in turn: ten round trips per chunk)
-        constexpr int NLD = (FC_CW * 20 * 16 + 255) / 256;              // loads per thread at H = 20 (more rows: second pass)
-        for (int base = 0; base < rows * 16; base += NLD * 256) {
-            fc_f4 pre[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int i = min(base + tid + 256 * u, rows * 16 - 1);
-                const int row = i >> 4, c4 = i & 15;
-                const int wi = row / H, hr = row - wi * H;
-                pre[u] = *reinterpret_cast<const fc_f4 *>(a.Xf + (((size_t)(b0 + wi) * FC_NP + fp) * H + hr) * 64 + 4 * c4);
-            }
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int i = base + tid + 256 * u;
-                if (i >= rows * 16) continue;
-                const int row = i >> 4, c4 = i & 15;
-                const fc_f4 v = pre[u] * sa_s[row / H];
-                const fc_h4 hh = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                const fc_h4 ll = {(_Float16)((v.x - (float)hh.x) * FC_LSCALE), (_Float16)((v.y - (float)hh.y) * FC_LSCALE),
-                                  (_Float16)((v.z - (float)hh.z) * FC_LSCALE), (_Float16)((v.w - (float)hh.w) * FC_LSCALE)};
-                *reinterpret_cast<fc_h4 *>(ah + (size_t)row * FC_APITCH + 4 * c4) = hh;
-                *reinterpret_cast<fc_h4 *>(al + (size_t)row * FC_APITCH + 4 * c4) = ll;
-            }
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + 256 * u;
+            if (i >= rows * 16) continue;
+            const int row = i >> 4, c4 = i & 15;
+            const fc_f4 v = pre[u] * sa_s[rwin[row]];
+            const fc_h4 hh = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            const fc_h4 ll = {(_Float16)((v.x - (float)hh.x) * FC_LSCALE), (_Float16)((v.y - (float)hh.y) * FC_LSCALE),
+                              (_Float16)((v.z - (float)hh.z) * FC_LSCALE), (_Float16)((v.w - (float)hh.w) * FC_LSCALE)};
+            *reinterpret_cast<fc_h4 *>(ah + (size_t)row * FC_APITCH + 4 * c4) = hh;
+            *reinterpret_cast<fc_h4 *>(al + (size_t)row * FC_APITCH + 4 * c4) = ll;
         }
         __syncthreads();
+        // the next chunk's activations travel while this one is multiplied
+        if (it + 1 < a.nchunk_per_wg && chunk + 1 < nchunks) fetch(chunk + 1);
         const int n_mt = (rows + 15) >> 4;
+        unsigned char *ybase = reinterpret_cast<unsigned char *>(a.Yf + ((size_t)b0 * FC_NP + fp) * H * 64);
+        float *pt = patch + wid * 16 * FC_OPITCH;
         for (int mt = wm; mt < n_mt; mt += 2) {
-            const int r = 16 * mt + (lane & 15);            // this lane's A row
-            const int hrow = r % H;
+            const int r = min(16 * mt + (lane & 15), rows_cap - 1);          // this lane's A row
+            const int hrow = rh[r];
+            const bool rin = 16 * mt + (lane & 15) < rows;
             fc_f4 hi[2], lo[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) { hi[nt] = fc_f4{0.f, 0.f, 0.f, 0.f}; lo[nt] = fc_f4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy) {
                 const int hs = hrow + dy - 1;
-                const bool ok = r < rows && hs >= 0 && hs < H;
-                const int rs = ok ? r + dy - 1 : 0;
+                const int rs = (rin && hs >= 0 && hs < H) ? r + dy - 1 : rows_cap;       // the zero row outside the image
+                const _Float16 *pa = ah + (size_t)rs * FC_APITCH + 8 * (lane >> 4), *pl = al + (size_t)rs * FC_APITCH + 8 * (lane >> 4);
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
                     const int ks = 2 * dy + s_;
-                    fc_h8 fa = *reinterpret_cast<const fc_h8 *>(ah + (size_t)rs * FC_APITCH + 32 * s_ + 8 * (lane >> 4));
-                    fc_h8 fl = *reinterpret_cast<const fc_h8 *>(al + (size_t)rs * FC_APITCH + 32 * s_ + 8 * (lane >> 4));
-                    if (!ok) {
-                        fa = fc_h8{0, 0, 0, 0, 0, 0, 0, 0};
-                        fl = fa;
-                    }
+                    const fc_h8 fa = *reinterpret_cast<const fc_h8 *>(pa + 32 * s_);
+                    const fc_h8 fl = *reinterpret_cast<const fc_h8 *>(pl + 32 * s_);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         hi[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, bh[ks][nt], hi[nt], 0, 0, 0);
@@ -352,19 +392,26 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
                     }
                 }
             }
-            // D: column n = lane & 15, rows 4 (lane >> 4) + e
+            // D (column n = lane & 15, rows 4 (lane >> 4) + e) goes through the wave's LDS patch so that every lane stores
+            // 16 bytes and a row's 32 columns leave as one 128-byte line
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = 16 * (2 * wn + nt) + (lane & 15);
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ro = 16 * mt + 4 * (lane >> 4) + e;
-                    const int wi = ro / H, hr = ro - wi * H;
-                    if (ro < rows)
-                        a.Yf[(((size_t)(b0 + wi) * FC_NP + fp) * H + hr) * 64 + n] =
-                            (hi[nt][e] + lo[nt][e] * (1.0f / FC_LSCALE)) * sa_s[FC_CW + wi];
+                for (int e = 0; e < 4; ++e)
+                    pt[(4 * (lane >> 4) + e) * FC_OPITCH + 16 * nt + (lane & 15)] = hi[nt][e] + lo[nt][e] * (1.0f / FC_LSCALE);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int rr = 8 * half + (lane >> 3), ro = 16 * mt + rr;
+                fc_f4 v = *reinterpret_cast<const fc_f4 *>(pt + rr * FC_OPITCH + 4 * (lane & 7));
+                if (ro < rows) {
+                    v *= sa_s[FC_CW + rwin[ro]];
+                    fc_at<fc_f4>(ybase, roff[ro] + (unsigned)((32 * wn + 4 * (lane & 7)) * 4)) = v;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -482,7 +529,16 @@ void amt_fftconv_layer_destroy_internal(amt_fftconv_layer *L) {
 
 size_t amt_fftconv_freq_floats(int B, int H) { return (size_t)FC_NP * B * H * 64; }
 
-static const size_t FC_ROW_LDS = (size_t)(16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+static const size_t FC_ROW_LDS = (size_t)(2 * 16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+// persistent row kernels: `per_cu` workgroups per CU (what their registers / LDS allow)
+static int fc_row_grid(int per_cu) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus * per_cu;
+}
 
 int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size_t in_stride, int B, int H, int W,
                             float *Xf, float *amaxf, hipStream_t st) {
@@ -496,14 +552,17 @@ int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size
     AMT_HIP_CHECK(hipMemsetAsync(amaxf, 0, (size_t)B * sizeof(float), st));
     FcRowArgs a{};
     a.in_sp = in_sp; a.in_stride = in_stride; a.Xf = Xf; a.amaxf = amaxf; a.tw = L->tw; a.B = B; a.H = H; a.W = W;
-    fc_row_kernel<false><<<B * H, FC_THREADS, FC_ROW_LDS, st>>>(a);
+    fc_row_kernel<false><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
 int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *amaxf, int B, int H, float *Yf, hipStream_t st) {
     if (!L || !Xf || !Yf || !amaxf) return AMT_E_INVALID;
-    const size_t lds = (size_t)2 * FC_CW * H * FC_APITCH * sizeof(_Float16) + 2 * FC_CW * sizeof(float);
+    if (H > 20) return AMT_E_UNSUPPORTED;
+    const size_t rows_cap = (size_t)FC_CW * H;
+    const size_t lds = 2 * (rows_cap + 1) * FC_APITCH * sizeof(_Float16) + (size_t)4 * 16 * FC_OPITCH * 4 + 2 * FC_CW * 4 + rows_cap * 4 +
+                       2 * rows_cap + 16;
     static size_t attr = 0;
     if (lds > attr) {
         AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -529,7 +588,7 @@ int amt_fftconv_inverse_epilogue(const amt_fftconv_layer *L, const float *Yf, co
     a.s1 = ep.s1; a.t1 = ep.t1; a.s2 = ep.s2; a.t2 = ep.t2; a.sc = ep.sc; a.sc_stride = ep.sc_stride;
     a.sc1 = ep.sc1; a.sc1_stride = ep.sc1_stride; a.sc1_w = ep.sc1_w; a.sc1_s = ep.sc1_s; a.sc1_t = ep.sc1_t;
     a.tw = L->tw; a.B = B; a.H = H; a.W = W;
-    fc_row_kernel<true><<<B * H, FC_THREADS, FC_ROW_LDS, st>>>(a);
+    fc_row_kernel<true><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
