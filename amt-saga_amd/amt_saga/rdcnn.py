@@ -32,9 +32,10 @@ from . import _lib
 from .device import empty, ptr, require_gpu, stream_ptr, to_dev
 
 
-# convolution arithmetic (all f32-equivalent): 2 = split-fp16 (3 f16 MFMAs per product block, default),
-# 1 = split-bf16 (6 bf16 MFMAs), 0 = f32 MFMA
-DEFAULT_MODE = int(os.environ.get('AMT_CONV_MODE', '2'))
+# convolution arithmetic (all f32-equivalent): 3 (default) = split-fp16 (3 f16 MFMAs per product block) with the
+# 32 -> 32 (4 x 16) layers on the timing heads' large images in the FFT domain (amt_fftconv.hip), 2 = split-fp16
+# everywhere, 1 = split-bf16 (6 bf16 MFMAs), 0 = f32 MFMA
+DEFAULT_MODE = int(os.environ.get('AMT_CONV_MODE', '3'))
 
 # BatchNorm statistics / last-Dense scaling that make the seeded synthetic heads input-sensitive
 # (tests/golden/gen_synthetic_calibration.py); keys "<topology signature>/<tensor name>"
@@ -315,8 +316,9 @@ class res_net:
         return float(self._lib.amt_rdcnn_flops_per_window(self._net))
 
     def set_mode(self, mode):
-        """0 = f32 MFMA convolutions, 1 = split-bf16 (6 bf16 MFMAs per product block),
-        2 = split-fp16 (3 f16 MFMAs per product block); all f32-equivalent."""
+        """0 = f32 MFMA convolutions, 1 = split-bf16 (6 bf16 MFMAs per product block), 2 = split-fp16 (3 f16 MFMAs per
+        product block), 3 = split-fp16 + the FFT-domain form of the 32 -> 32 (4 x 16) layers on images of at most 20 x 561
+        (nets without such layers run exactly as in mode 2); all f32-equivalent."""
         self.mode = int(mode)
         if self._net is not None:
             _lib.check(self._lib.amt_rdcnn_set_mode(self._net, self.mode))

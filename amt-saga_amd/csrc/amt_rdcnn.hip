@@ -1352,7 +1352,7 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     amt_rdcnn_destroy(n);
                     return AMT_E_UNSUPPORTED;
                 }
-                if (kh == 4 && kw == 16 && C == 32 && fo == 32 && W + 15 <= 576)
+                if (kh == 4 && kw == 16 && C == 32 && fo == 32 && W + 15 <= 576 && H <= 20)
                     c.k_host.assign(kern, kern + (size_t)kh * kw * C * fo);      // FFT-domain form, built on demand (mode 3)
                 const int NT = fo / 32, nch = C / 32, ntap = kh * kw;
                 // small late-stage layers (few output positions per window) cannot fill 256 CUs with

@@ -199,8 +199,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the f32-MFMA and H2D-inclusive legs (profiling runs)')
-    ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1, 2),
-                    help='convolution arithmetic: 2 = split-fp16 (default), 1 = split-bf16, 0 = f32 MFMA; all f32-equivalent')
+    ap.add_argument('--conv-mode', type=int, default=None, choices=(0, 1, 2, 3),
+                    help='convolution arithmetic: 3 = FFT-domain form of the 4 x 16 layers on the large images + split-fp16 elsewhere '
+                         '(default), 2 = split-fp16 everywhere, 1 = split-bf16, 0 = f32 MFMA; all f32-equivalent')
     args = ap.parse_args()
 
     from amt_saga import dist as adist, synth
@@ -287,23 +288,47 @@ def main():
         a['ms'] += r['ms']
         a['flops'] += r['flops_per_window'] * r['windows']
         a['windows'] += r['windows']
-    dom_key = max(by_class, key=lambda k: by_class[k]['ms'])
+    # conv mode 3: the 32 -> 32 (4 x 16) layers on the large images run in the FFT domain (three kernels per layer, timed
+    # together by the per-layer events); the roofline object stays on the dominant SINGLE kernel -- the largest direct
+    # split-fp16 class -- and the FFT-domain layers get their own object (roofline_fft: bound by the HBM traffic of the
+    # frequency tensors)
+    fft_keys = [k for k in by_class if conv_mode == 3 and k[:4] == (4, 16, 32, 32) and k[5] + 15 <= 576 and k[4] <= 20]
+    direct = {k: v for k, v in by_class.items() if k not in fft_keys} or by_class
+    dom_key = max(direct, key=lambda k: direct[k]['ms'])
     dom = by_class[dom_key]
     conv_ms_total = sum(a['ms'] for a in by_class.values())
     achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-    split = conv_mode >= 1 and dom_key[2] <= 64
-    nmf = 3 if conv_mode == 2 else 6                       # MFMAs per f32-equivalent product block
+    arith = 2 if conv_mode == 3 else conv_mode
+    split = arith >= 1 and dom_key[2] <= 64
+    nmf = 3 if arith == 2 else 6                           # MFMAs per f32-equivalent product block
     # split modes: every algorithmic f32 MAC costs nmf f16 / bf16 MFMA MACs, so the MFMA roof for the
     # ALGORITHMIC flops of this kernel is the dense 16-bit peak / nmf
     peak_tf = round(MFMA_BF16_PEAK_TF / nmf, 1) if split else MFMA_F32_PEAK_TF
-    if split and conv_mode == 2 and dom_key[3] == 32:
+    if split and arith == 2 and dom_key[3] == 32:
         kname = ('conv_f16x3s_kernel<%d,%d,%d> (Cout %d) on %dx%d (3 x v_mfma_f32_16x16x32_f16 per f32 product '
                  'block of a tap pair)') % dom_key
     else:
         kname = (('conv_f16x3s_kernel<%d,%d,%d> (Cout %d, 32-wide N-slices) on %dx%d (3 x v_mfma_f32_16x16x32_f16 per f32 product block)'
-                  if conv_mode == 2 else
+                  if arith == 2 else
                   'conv_bf16x6_kernel<%d,%d,%d,%d> on %dx%d (6 x v_mfma_f32_32x32x16_bf16 per f32 product block)')
                  if split else 'conv_mfma_kernel<%d,%d,%d,%d> on %dx%d (v_mfma_f32_32x32x2_f32)') % dom_key
+    roofline_fft = None
+    if fft_keys:
+        fk = max(fft_keys, key=lambda k: by_class[k]['ms'])
+        fa = by_class[fk]
+        Hh, Ww = fk[4], fk[5]
+        # algorithmic HBM bytes of one chained layer and window: read Xf, write Yf (GEMM); read Yf, write Xf (inverse +
+        # epilogue + forward); every second layer also reads a shortcut and writes its spatial output
+        freq = 289 * Hh * 64 * 4
+        spat = Hh * Ww * 32 * 4
+        per_layer_window = 4 * freq + spat
+        gbs = per_layer_window * fa['windows'] / (fa['ms'] * 1e-3) / 1e9
+        roofline_fft = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                            traffic=None, kernel='fc_gemm_kernel + fc_row_kernel<true> per layer (amt_fftconv.hip), %dx%d 32->32 (4x16)' % (Hh, Ww),
+                            algorithmic_bytes_per_layer_window=per_layer_window,
+                            ms_per_layer_per_1024_windows=round(fa['ms'] / (fa['windows'] / 1024.0), 3),
+                            direct_form_equivalent_tflops=round(fa['flops'] / (fa['ms'] * 1e-3) / 1e12, 1),
+                            share_of_conv_time=round(fa['ms'] / conv_ms_total, 3))
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     pmc = {}
@@ -312,7 +337,7 @@ def main():
             # per-launch HBM bytes of the step's OWN launch of each kernel (selected by grid size,
             # scripts/make_pmc_traffic.py), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
             pmc = json.load(open(tf))
-            t = pmc.get(('conv_f16x3' if conv_mode == 2 else 'conv_bf16x6') if split else 'conv_mfma')
+            t = pmc.get(('conv_f16x3' if arith == 2 else 'conv_bf16x6') if split else 'conv_mfma')
             if t and t.get('windows_per_launch'):
                 traffic = int(t['hbm_bytes_per_launch'] * min(B, 1024) / t['windows_per_launch'])
         except Exception:
@@ -324,7 +349,7 @@ def main():
     # copied verbatim from profiles/pmc_derived.json under `from_profiles`, with the files and the commit it was
     # collected at (scripts/collect_profiles.sh writes it; absent file -> null).
     sustained = {}
-    if split and conv_mode == 2 and not args.no_extras:
+    if split and arith == 2 and not args.no_extras:
         import ctypes as C
         from amt_saga import _lib as alib
         tf_, ms_ = C.c_double(0.0), C.c_double(0.0)
@@ -459,12 +484,13 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {0: 'f32', 1: 'f32 (conv: split-bf16 x3 operands, f32 accumulate)',
-                      2: 'f32 (conv: split-fp16 x2 operands, f32 accumulate)'}[conv_mode],
+                      2: 'f32 (conv: split-fp16 x2 operands, f32 accumulate)',
+                      3: 'f32 (conv: split-fp16 x2 operands, f32 accumulate; 4x16 layers on the large images in the FFT domain)'}[conv_mode],
             'data': 'synthetic (additive-synth windows, seeded synthetic weights with calibrated BN statistics)',
             'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
                        'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
                        'parallelism': 'windows sharded x%d, event all-gather' % world},
-            'roofline': roofline, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_fft': roofline_fft, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
             'prepare_ms': round(prepare_ms, 1),
             'events_checksum': int(events.to(torch.int64).sum().item()),
             'distinct_decisions': {k: int(torch.unique(events[:, c]).numel())
@@ -477,7 +503,8 @@ def main():
                    'range scaling from measured maxima), 3 MFMAs per product block, f32 accumulate, ~1e-7 rms / <= 2^-21 '
                    'worst case per product; same parity bars as --conv-mode 0 (tests/test_gpu_rdcnn.py); value_f32_mfma '
                    'is the same step on the f32 MFMA',
-            }[conv_mode],
+            }[arith] + (' The 32->32 (4x16) layers on the 20x516 images run in the FFT domain (amt_fftconv.hip): 576-point f32 FFTs '
+                        'of channel pairs, per-frequency-pair GEMMs in the same split-fp16 arithmetic; same parity bars.' if conv_mode == 3 else ''),
         }
         out.update(extras)
         if cpu:

@@ -161,15 +161,17 @@ def test_timing_head_n2048_batch_independent(env):
     h.set_mode(0)
 
 
-def test_large_batch_grid(env):
-    """A 70-window batch of the timing head (thousands of workgroups per launch, XCD-swizzled tile
-    order): outputs bit-identical to a small batch of the same windows, deterministic, and within
-    2e-5 of the f32-MFMA mode; a ragged window count gives the same per-window results."""
+@pytest.mark.parametrize('mode', [2, 3])
+def test_large_batch_grid(env, mode):
+    """A 70-window batch of the timing head (thousands of workgroups per launch, XCD-swizzled tile order; in mode 3
+    GEMM chunks of eight windows whose 16-row tiles straddle windows, two image rows per row-transform workgroup):
+    outputs bit-identical to a small batch of the same windows, deterministic, and within 2e-5 of the f32-MFMA
+    mode; a ragged window count gives the same per-window results."""
     torch = env['torch']
     p = env['hp'].Hyperparams(N=2048)
     h = env['heads'].timming_classifier(p)
     x = torch.from_numpy(_inputs((20, 516), 70, 17)).cuda()
-    h.set_mode(2)
+    h.set_mode(mode)
     big, lbig = h.predict_device([x], return_logits=True)
     small, lsmall = h.predict_device([x[5:12].contiguous()], return_logits=True)
     assert torch.equal(lbig[5:12], lsmall)
@@ -179,10 +181,12 @@ def test_large_batch_grid(env):
     ref, lref = h.predict_device([x], return_logits=True)
     assert float((lbig - lref).abs().max()) / max(float(lref.abs().max()), 1.0) < 2e-5
     assert float((big - ref).abs().max()) / float(ref.abs().max()) < 2e-5
-    # ragged tail: a window count that does not fill the last workgroup's run of tiles
-    h.set_mode(2)
+    # ragged tail: a window count that does not fill the last workgroup's run of tiles / the last chunk of eight
+    h.set_mode(mode)
     odd, lodd = h.predict_device([x[:37].contiguous()], return_logits=True)
     assert torch.equal(lodd, lbig[:37])
+    one, lone = h.predict_device([x[36:37].contiguous()], return_logits=True)
+    assert torch.equal(lone, lbig[36:37])
 
 
 def test_split_fp16_operand_range(env):
