@@ -240,9 +240,12 @@ __global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) 
             *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (k1 * 24 + n2) * 2) = v;
         }
         __syncthreads();
-        const int k1 = j24;
+        int k1 = j24, cp = c16;
+        // (opaque copies: the 24 store offsets below depend only on thread constants, and hipcc otherwise computes them at
+        // the top of the kernel and carries them -- through scratch memory -- across all four transforms)
+        asm volatile("" : "+v"(k1), "+v"(cp));
 #pragma unroll
-        for (int n = 0; n < 24; ++n) x[n] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (k1 * 24 + n) * 2);
+        for (int n = 0; n < 24; ++n) x[n] = *reinterpret_cast<const float2 *>(buf + cp * FC_PS + (k1 * 24 + n) * 2);
         fc_fft24<false>(x);
         float fmax_ = 0.f;
         float *xb = a.Xf + ((size_t)b * FC_NP * a.H + h) * 64;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) 
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            const unsigned int off = (unsigned)((fp * a.H * 64 + 2 * c16) * 4);
+            const unsigned int off = (unsigned)((fp * a.H * 64 + 2 * cp) * 4);
             fc_at<float2>(xb, off + side * 128) = x[k2];
             if (f == 0 || f == FC_NF / 2) fc_at<float2>(xb, off + 128) = x[k2];          // self-paired bins fill both sides
             fmax_ = fmaxf(fmax_, fmaxf(fabsf(x[k2].x), fabsf(x[k2].y)));

@@ -12,8 +12,11 @@ RDCNN heads -> note decision -> guess lookup -> subtract] -> event gather.
 Weak scaling: every rank processes the same number of windows.
 
 Prints ONE JSON line on rank 0 with the driver contract plus
-  roofline      dominant kernel (timing-head convolution on the matrix pipe): achieved TFLOP/s from
-                HIP events recorded around every conv launch inside the timed region
+  roofline      dominant kernel(s) of the step, timed with HIP events recorded around every conv layer inside the timed
+                region: conv mode 3 (default) -- the FFT-domain form of the timing heads' 4 x 16 layers (fc_gemm_kernel +
+                fc_row_kernel per layer): algorithmic HBM bytes of the frequency tensors / time; modes 0-2 -- the
+                largest direct convolution class on the matrix pipe: algorithmic TFLOP/s
+  roofline_mfma (mode 3) the largest DIRECT split-fp16 convolution class, as `roofline` reports it in mode 2
   roofline_stft the north-star HBM kernel pair (STFT->mag(/phase)/max, subtract): algorithmic GB/s over the
                 bytes the step CONSUMES (no phase plane when no iteration reads it), HIP events on the launch stream
   cpu_baseline  the numpy oracle ("port") timed on this host on a bounded sample: one process x one thread,
@@ -490,7 +493,12 @@ def main():
             'config': {'workload': wl['name'], 'windows_per_gpu': B, 'n_fft': p.N, 'hop': p.H,
                        'frames': T, 'iters': wl['iters'], 'heads': list(wl['heads']),
                        'parallelism': 'windows sharded x%d, event all-gather' % world},
-            'roofline': roofline, 'roofline_fft': roofline_fft, 'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
+            # the dominant kernel(s) of the step: in conv mode 3 the FFT-domain layer pair (GEMM + row transforms; bound by
+            # the HBM traffic of the frequency tensors), else the largest direct convolution class (matrix pipe), which in
+            # mode 3 is reported as roofline_mfma
+            'roofline': roofline_fft if (roofline_fft and roofline_fft['share_of_conv_time'] > roofline['share_of_conv_time']) else roofline,
+            'roofline_mfma': roofline if (roofline_fft and roofline_fft['share_of_conv_time'] > roofline['share_of_conv_time']) else None,
+            'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
             'prepare_ms': round(prepare_ms, 1),
             'events_checksum': int(events.to(torch.int64).sum().item()),
             'distinct_decisions': {k: int(torch.unique(events[:, c]).numel())
