@@ -25,6 +25,7 @@
 #include "amt_fftconv.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #define FC_NF 576
@@ -32,6 +33,7 @@
 #define FC_PS 1160                      // dwords per channel pair in the LDS transposition buffer (576 complex + 8 pad)
 #define FC_THREADS 384                  // 16 channel pairs x 24
 #define FC_LSCALE 2048.0f
+#define FC_DEFAULT_LAYOUT 0
 
 typedef _Float16 fc_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fc_h4 __attribute__((ext_vector_type(4)));
@@ -89,6 +91,7 @@ struct FcRowArgs {
     const float *sc1_w, *sc1_s, *sc1_t;          // ... its 1x1 kernel and folded BN [32]
     const float2 *tw;                            // [576] e^{-2 pi i m / 576}
     int B, H, W;
+    int sf, sh;                                  // float strides of the frequency tensors: pair fp, image row h (window: 289 H 64)
 };
 
 __device__ __forceinline__ float fc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) 
     if (IN_FREQ) {
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
         const int k1 = j24;
-        const float *yb = a.Yf + ((size_t)b * FC_NP * a.H + h) * 64;
+        const float *yb = a.Yf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            x[k2] = fc_at<float2>(yb, (unsigned)((fp * a.H * 64 + side * 32 + 2 * c16) * 4));
+            x[k2] = fc_at<float2>(yb, (unsigned)((fp * a.sf + side * 32 + 2 * c16) * 4));
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
@@ -248,12 +251,12 @@ __global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) 
         for (int n = 0; n < 24; ++n) x[n] = *reinterpret_cast<const float2 *>(buf + cp * FC_PS + (k1 * 24 + n) * 2);
         fc_fft24<false>(x);
         float fmax_ = 0.f;
-        float *xb = a.Xf + ((size_t)b * FC_NP * a.H + h) * 64;
+        float *xb = a.Xf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
             const int f = k1 + 24 * k2;
             const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            const unsigned int off = (unsigned)((fp * a.H * 64 + 2 * cp) * 4);
+            const unsigned int off = (unsigned)((fp * a.sf + 2 * cp) * 4);
             fc_at<float2>(xb, off + side * 128) = x[k2];
             if (f == 0 || f == FC_NF / 2) fc_at<float2>(xb, off + 128) = x[k2];          // self-paired bins fill both sides
             fmax_ = fmaxf(fmax_, fmaxf(fabsf(x[k2].x), fabsf(x[k2].y)));
@@ -278,6 +281,7 @@ struct FcGemmArgs {
     const _Float16 *gw;                  // [289][8 k-steps][2 planes][64 n][32 k]
     const int *gsw;                      // [289] weights of pair fp were scaled by 2^gsw
     int B, H, nchunk_per_wg;
+    int sf, sh;                          // float strides of the frequency tensors: pair fp, image row h
 };
 
 __device__ __forceinline__ int fc_scale_exp(float amax) {
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     // row tables (the same for every chunk) and the zero row the out-of-image taps read
     for (int r = tid; r < rows_cap; r += 256) {
         const int wi = r / H, hr = r - wi * H;
-        roff[r] = (unsigned int)(((size_t)wi * FC_NP * H + hr) * 64 * 4);
+        roff[r] = (unsigned int)(((size_t)wi * FC_NP * H * 64 + (size_t)hr * a.sh) * 4);
         rwin[r] = (unsigned char)wi; rh[r] = (unsigned char)hr;
     }
     if (tid < FC_APITCH) { ah[(size_t)rows_cap * FC_APITCH + tid] = (_Float16)0.f; al[(size_t)rows_cap * FC_APITCH + tid] = (_Float16)0.f; }
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
     auto fetch = [&](int chunk) {                           // a chunk's activations -> registers (clamped addresses, no branch)
         const int b0 = chunk * FC_CW;
         const int rows = min(FC_CW, a.B - b0) * H;
-        const unsigned char *base = reinterpret_cast<const unsigned char *>(a.Xf + ((size_t)b0 * FC_NP + fp) * H * 64);
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(a.Xf + (size_t)b0 * FC_NP * H * 64 + (size_t)fp * a.sf);
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int i = min(tid + 256 * u, rows * 16 - 1);
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcGemmArgs a) {
         // the next chunk's activations travel while this one is multiplied
         if (it + 1 < a.nchunk_per_wg && chunk + 1 < nchunks) fetch(chunk + 1);
         const int n_mt = (rows + 15) >> 4;
-        unsigned char *ybase = reinterpret_cast<unsigned char *>(a.Yf + ((size_t)b0 * FC_NP + fp) * H * 64);
+        unsigned char *ybase = reinterpret_cast<unsigned char *>(a.Yf + (size_t)b0 * FC_NP * H * 64 + (size_t)fp * a.sf);
         float *pt = patch + wid * 16 * FC_OPITCH;
         for (int mt = wm; mt < n_mt; mt += 2) {
             const int r = min(16 * mt + (lane & 15), rows_cap - 1);          // this lane's A row
@@ -532,6 +536,14 @@ void amt_fftconv_layer_destroy_internal(amt_fftconv_layer *L) {
 
 size_t amt_fftconv_freq_floats(int B, int H) { return (size_t)FC_NP * B * H * 64; }
 
+// layout of a window's [289 pairs][H rows][64] block: pair-major (AMT_FC_LAYOUT=0: a GEMM workgroup reads H x 256 contiguous
+// bytes per pair) or row-major (1: a row transform reads and writes 74 KB contiguous, the GEMM 256-byte pieces)
+static void fc_strides(int H, int *sf, int *sh) {
+    static int layout = -1;
+    if (layout < 0) { const char *e = getenv("AMT_FC_LAYOUT"); layout = e ? atoi(e) : FC_DEFAULT_LAYOUT; }
+    if (layout == 1) { *sf = 64; *sh = FC_NP * 64; } else { *sf = H * 64; *sh = 64; }
+}
+
 static const size_t FC_ROW_LDS = (size_t)(2 * 16 * FC_PS) * 4 + FC_NF * sizeof(float2);
 // persistent row kernels: `per_cu` workgroups per CU (what their registers / LDS allow)
 static int fc_row_grid(int per_cu) {
@@ -555,6 +567,7 @@ int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size
     AMT_HIP_CHECK(hipMemsetAsync(amaxf, 0, (size_t)B * sizeof(float), st));
     FcRowArgs a{};
     a.in_sp = in_sp; a.in_stride = in_stride; a.Xf = Xf; a.amaxf = amaxf; a.tw = L->tw; a.B = B; a.H = H; a.W = W;
+    fc_strides(H, &a.sf, &a.sh);
     fc_row_kernel<false><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
@@ -574,7 +587,8 @@ int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *a
     const int nchunks = (B + FC_CW - 1) / FC_CW;
     int per = 1;
     while ((size_t)((nchunks + per - 1) / per) * FC_NP > 4096 && per < 16) per *= 2;      // ~2 resident rounds of workgroups
-    FcGemmArgs a{Xf, Yf, amaxf, L->gw, L->gsw, B, H, per};
+    FcGemmArgs a{Xf, Yf, amaxf, L->gw, L->gsw, B, H, per, 0, 0};
+    fc_strides(H, &a.sf, &a.sh);
     fc_gemm_kernel<<<dim3(FC_NP, (nchunks + per - 1) / per), 256, lds, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
@@ -591,6 +605,7 @@ int amt_fftconv_inverse_epilogue(const amt_fftconv_layer *L, const float *Yf, co
     a.s1 = ep.s1; a.t1 = ep.t1; a.s2 = ep.s2; a.t2 = ep.t2; a.sc = ep.sc; a.sc_stride = ep.sc_stride;
     a.sc1 = ep.sc1; a.sc1_stride = ep.sc1_stride; a.sc1_w = ep.sc1_w; a.sc1_s = ep.sc1_s; a.sc1_t = ep.sc1_t;
     a.tw = L->tw; a.B = B; a.H = H; a.W = W;
+    fc_strides(H, &a.sf, &a.sh);
     fc_row_kernel<true><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
