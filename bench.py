@@ -326,8 +326,15 @@ def main():
         spat = Hh * Ww * 32 * 4
         per_layer_window = 4 * freq + spat
         gbs = per_layer_window * fa['windows'] / (fa['ms'] * 1e-3) / 1e9
+        fft_traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            fft_traffic = int((pj['fc_gemm']['hbm_bytes_per_launch'] / pj['fc_gemm']['windows_per_launch'] +
+                               pj['fc_row']['hbm_bytes_per_launch'] / pj['fc_row']['windows_per_launch']) * min(B, 1024))
+        except Exception:
+            fft_traffic = None
         roofline_fft = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
-                            traffic=None, kernel='fc_gemm_kernel + fc_row_kernel<true> per layer (amt_fftconv.hip), %dx%d 32->32 (4x16)' % (Hh, Ww),
+                            traffic=fft_traffic, kernel='fc_gemm_kernel + fc_row_kernel<true> per layer (amt_fftconv.hip), %dx%d 32->32 (4x16)' % (Hh, Ww),
                             algorithmic_bytes_per_layer_window=per_layer_window,
                             ms_per_layer_per_1024_windows=round(fa['ms'] / (fa['windows'] / 1024.0), 3),
                             direct_form_equivalent_tflops=round(fa['flops'] / (fa['ms'] * 1e-3) / 1e12, 1),
