@@ -74,6 +74,7 @@ struct HxScale {
     float *amax_out;          // device [B] or null: max |output| per window (atomicMax, zeroed by the caller)
     int sw;                   // weights were scaled by 2^sw on the host
     unsigned long long *ts;   // diagnostic (AMT_CONV_TS): four 100-MHz timestamps per workgroup, or null
+    const int *sw_dev = nullptr;   // TRAIN form: the weight exponent lives on the device (the weights move every step)
 };
 #define HX_MAXWIN 64                         // windows per workgroup tile (masked tiles of >= 4 positions)
 
@@ -123,7 +124,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 // MS = 16-position M-subtiles per wave: 2 (eight waves, 512 threads, four waves per SIMD) or 4 (four waves of 64
 // positions, 256 threads, two waves per SIMD with twice the registers: a B fragment then feeds four M-subtiles
 // instead of two -- 12 ds_read_b128 per 24 MFMAs instead of 8 per 12).
-template <int KH, int KW, int CIN, bool MASKED, int MS = 2>
+// TRAIN = true is the trainer's form (amt_train.hip: forward convolution and data gradient of a training step): the
+// epilogue leaves the raw sum (+ bias, + an optional accumulate-into tensor through the shortcut slot) instead of
+// sigmoid(BN(.)), the padding before the image is a runtime value (the data gradient is the correlation with the
+// flipped kernel, whose "same" padding is the mirror image: KH - 1 - (KH - 1) / 2 rows before), and the weight
+// exponent is read from the device.  The inference instantiations (TRAIN = false) compile exactly as before.
+template <int KH, int KW, int CIN, bool MASKED, int MS = 2, bool TRAIN = false>
 __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel(ConvParams p, const uint4 *__restrict__ w16s,
                                                                                   HxScale hs) {
     constexpr int NT = 1024 / MS;                                   // threads per workgroup (256 positions / (16 MS) waves)
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     constexpr int NCHUNK = CIN / BX_CC;
     constexpr int NTAPS = KH * KW;
     constexpr int PCAP = 256;
-    constexpr int PAD_T = (KH - 1) / 2, PAD_L = (KW - 1) / 2;
+    const int PAD_T = TRAIN ? p.pad_t : (KH - 1) / 2, PAD_L = TRAIN ? p.pad_l : (KW - 1) / 2;
     static_assert(NTAPS % 2 == 0, "tap pairs");
     constexpr int NSLAB = NTAPS / 2;                                // 4-KB slabs of two taps (host layout)
     constexpr int SLAB_V4 = 256;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     float my_bn = 0.f;
     if (tid < 128) {
         const float *src = tid < 32 ? p.s1 : tid < 64 ? p.t1 : tid < 96 ? p.s2 : p.t2;
-        my_bn = src ? src[cout_off + (tid & 31)] : (tid < 96 ? 1.f : 0.f);      // no residual BN: s2 = 1, t2 = 0
+        my_bn = src ? src[cout_off + (tid & 31)] : ((tid < 32 || (tid >= 64 && tid < 96)) ? 1.f : 0.f);   // absent: scale 1, shift 0
     }
     // v_mfma_f32_16x16x32_f16: A lane l = row l%16, k-group l/16 (8 k each); one MFMA contracts a
     // PAIR of taps x 16 channels: k-group g = (tap t + g%2, channels 8*(g/2) .. +7); the second tap
@@ -377,7 +383,8 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
     if (tid < PCAP) {                                      // 2^-(sa + sw) of every output row's window
         const int wl = min(max(pos_win[tid] - win0, 0), HX_MAXWIN - 1);
         const int sa = (int)(__float_as_uint(win_is[wl]) >> 23) - 127;
-        pos_os[tid] = __uint_as_float((unsigned)(127 - (sa + hs.sw)) << 23);
+        const int sw = TRAIN ? *hs.sw_dev : hs.sw;
+        pos_os[tid] = __uint_as_float((unsigned)(127 - (sa + sw)) << 23);
     }
     __syncthreads();
     float *tb = reinterpret_cast<float *>(in_lds) + wid * (16 * MS * HX_TPITCH);
@@ -397,8 +404,8 @@ __global__ __launch_bounds__(1024 / MS, MS == 2 ? 4 : 2) void conv_f16x3s_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = ms * 16 + 4 * (lane >> 4) + e;
-                tb[row * HX_TPITCH + ns * 16 + (lane & 15)] =
-                    sigmoidf_(((hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * osc[ms][e]) * s1 + t1);
+                const float z = (hi[ms][ns][e] + lo[ms][ns][e] * (1.0f / HX_LSCALE)) * osc[ms][e];
+                tb[row * HX_TPITCH + ns * 16 + (lane & 15)] = TRAIN ? z + t1 : sigmoidf_(z * s1 + t1);
             }
     }
     constexpr int NR = 2 * MS;                             // eight rows of the wave's patch per pass

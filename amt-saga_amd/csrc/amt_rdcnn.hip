@@ -28,6 +28,7 @@
 //     stores (a store instruction = two full 128-B channel rows).
 #include "amt_common.h"
 #include "amt_fftconv.h"
+#include "amt_convh.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -55,6 +56,7 @@ struct ConvParams {
     // tensor the epilogue forms (x * w_c) * s_c + t_c itself -- the operations of proj_kernel
     const float *sc1 = nullptr; size_t sc1_win_stride = 0;      // [B][H][W] (null: not used)
     const float *sc1_w = nullptr, *sc1_s = nullptr, *sc1_t = nullptr;   // [COUT]
+    int pad_t = 0, pad_l = 0;                    // TRAIN form of conv_f16x3s_kernel only: rows / columns of padding before the image
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -1794,3 +1796,131 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
 }
 
 }  // extern "C"
+
+// ---- trainer form of the split-fp16 kernels (amt_convh.h) --------------------------------------------------------
+int amt_convh_plan_init(amt_convh_plan *pl, int kh, int kw, int cin, int cout, int H, int W) {
+    if (!pl || !conv_supported(kh, kw)) return AMT_E_UNSUPPORTED;
+    if (!(cin == 32 || cin == 64 || cin == 128) || cout < 32 || cout % 32 != 0 || H < 1 || W < 1) return AMT_E_UNSUPPORTED;
+    ConvOp c;
+    c.cin = cin; c.cout = cout; c.H = H; c.W = W; c.kh = kh; c.kw = kw;
+    c.cwh = 32; c.nsliceh = cout / 32;
+    choose_tile_h(c);
+    if (c.THh <= 0) return AMT_E_UNSUPPORTED;
+    pl->kh = kh; pl->kw = kw; pl->cin = cin; pl->cout = cout; pl->H = H; pl->W = W;
+    pl->TH = c.THh; pl->TW = c.TWh; pl->NWIN = c.NWINh; pl->masked = c.maskedh ? 1 : 0; pl->lds = c.ldsh;
+    return AMT_OK;
+}
+size_t amt_convh_packed_bytes(const amt_convh_plan *pl) {
+    return (size_t)pl->kh * pl->kw * pl->cin * pl->cout * 2 /* planes */ * 2 /* bytes */;
+}
+
+__global__ __launch_bounds__(256) void convh_wmax_kernel(const amt_convh_pack_job *jobs) {
+    __shared__ float red[16];
+    const amt_convh_pack_job j = jobs[blockIdx.y];
+    const size_t n = (size_t)j.ntap * j.Cin * j.Cout;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(j.w[i]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(j.wmax), __float_as_int(m));
+}
+// one thread per (slice, chunk, tap pair, N-subtile, lane): eight channels x two planes = two 16-byte stores.
+// Layout (the host loop of amt_rdcnn_create, "split-fp16 weights"): [slice][chunk16][tap pair][plane][N-subtile][lane][8]
+__global__ __launch_bounds__(256) void convh_pack_kernel(const amt_convh_pack_job *jobs) {
+    const amt_convh_pack_job j = jobs[blockIdx.y];
+    const float wmax = *j.wmax;
+    int sw = 0;
+    if (wmax > 0.f && wmax < 3.0e38f) {
+        int ew = 0;
+        (void)frexpf(wmax, &ew);
+        sw = 4 - ew;
+    }
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) *j.sw = sw;
+    const float wscale = ldexpf(1.0f, sw);
+    const bool bwd = blockIdx.z == 1;
+    uint4 *out = static_cast<uint4 *>(bwd ? j.packed_bwd : j.packed_fwd);
+    if (!out) return;
+    const int C = bwd ? j.Cout : j.Cin, fo = bwd ? j.Cin : j.Cout;          // channels of the convolution that runs
+    const int nch16 = C / BX_CC, ntp = j.ntap / 2, nsl = fo / 32;
+    const size_t total = (size_t)nsl * nch16 * ntp * 2 * 64;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ln = (int)(q & 63);
+        size_t r = q >> 6;
+        const int ns = (int)(r & 1); r >>= 1;
+        const int tp = (int)(r % ntp); r /= ntp;
+        const int ch = (int)(r % nch16);
+        const int sl = (int)(r / nch16);
+        const int col = ln & 15, kg = ln >> 4;
+        const int tap = 2 * tp + (kg & 1);
+        const int co = sl * 32 + ns * 16 + col;
+        unsigned short h[2][8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int ci = ch * BX_CC + 8 * (kg >> 1) + jj;
+            const float wv = bwd ? j.w[((size_t)(j.ntap - 1 - tap) * j.Cin + co) * j.Cout + ci]
+                                 : j.w[((size_t)tap * j.Cin + ci) * j.Cout + co];
+            amt_split_f16<true>(wv * wscale, h[0][jj], h[1][jj]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint4 pk;
+            pk.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+            pk.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+            pk.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+            pk.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+            out[((((((size_t)sl * nch16 + ch) * ntp + tp) * 2 + pl) * 2 + ns) * 64) + ln] = pk;
+        }
+    }
+}
+int amt_convh_pack_all(const amt_convh_pack_job *jobs_dev, int n, int max_elems, hipStream_t st) {
+    if (n <= 0) return AMT_OK;
+    const unsigned gx = (unsigned)std::min<size_t>(((size_t)max_elems + 256 * 16 - 1) / (256 * 16), 64);
+    convh_wmax_kernel<<<dim3(gx, n), 256, 0, st>>>(jobs_dev);
+    convh_pack_kernel<<<dim3(gx, n, 2), 256, 0, st>>>(jobs_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+int amt_convh_absmax(const float *x, size_t n, int B, float *amax, hipStream_t st) {
+    absmax_kernel<<<dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 64), B), 256, 0, st>>>(x, n, n, amax);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+template <int KH, int KW, int CIN, bool MASKED>
+static int launch_convtr_t(const amt_convh_plan &pl, const ConvParams &p, const void *packed, const HxScale &hs, hipStream_t st) {
+    auto kern = conv_f16x3s_kernel<KH, KW, CIN, MASKED, 2, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AMT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(80 * 1024)));
+        attr_set = true;
+    }
+    const int groups = (p.B + p.NWIN - 1) / p.NWIN;
+    const unsigned grid = (unsigned)((size_t)groups * p.tiles_h * p.tiles_w);
+    kern<<<dim3(grid, pl.cout / 32), 512, pl.lds, st>>>(p, static_cast<const uint4 *>(packed), hs);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+template <int KH, int KW>
+static int launch_convtr_k(const amt_convh_plan &pl, const ConvParams &p, const void *packed, const HxScale &hs, hipStream_t st) {
+#define HXT_CASE(CI)                                                                            \
+    if (pl.cin == CI)                                                                           \
+        return pl.masked ? launch_convtr_t<KH, KW, CI, true>(pl, p, packed, hs, st)             \
+                         : launch_convtr_t<KH, KW, CI, false>(pl, p, packed, hs, st);
+    HXT_CASE(32) HXT_CASE(64) HXT_CASE(128)
+#undef HXT_CASE
+    return AMT_E_UNSUPPORTED;
+}
+int amt_convh_run(const amt_convh_plan *pl, const float *in, float *out, const float *acc, int B, const void *packed,
+                  const int *sw_dev, const float *bias, const float *amax_in, int pad_t, int pad_l, hipStream_t st) {
+    if (!pl || !in || !out || !packed || !sw_dev || !amax_in || B <= 0) return AMT_E_INVALID;
+    if (pad_t < 0 || pad_t >= pl->kh || pad_l < 0 || pad_l >= pl->kw) return AMT_E_INVALID;
+    const size_t istr = (size_t)pl->H * pl->W * pl->cin, ostr = (size_t)pl->H * pl->W * pl->cout;
+    ConvParams p{in, istr, out, ostr, acc, ostr, nullptr, nullptr, bias, nullptr, nullptr,
+                 B, pl->H, pl->W, pl->TH, pl->TW, pl->NWIN, (pl->H + pl->TH - 1) / pl->TH, (pl->W + pl->TW - 1) / pl->TW, pl->cout};
+    p.pad_t = pad_t; p.pad_l = pad_l;
+    HxScale hs{amax_in, nullptr, 0, nullptr};
+    hs.sw_dev = sw_dev;
+    if (pl->kh == 4 && pl->kw == 16) return launch_convtr_k<4, 16>(*pl, p, packed, hs, st);
+    if (pl->kh == 4 && pl->kw == 2) return launch_convtr_k<4, 2>(*pl, p, packed, hs, st);
+    if (pl->kh == 2 && pl->kw == 2) return launch_convtr_k<2, 2>(*pl, p, packed, hs, st);
+    return AMT_E_UNSUPPORTED;
+}

@@ -152,3 +152,37 @@ def test_timing_head_train_on_batch_vs_oracle(env):
     w0 = {k: v.copy() for k, v in h.weights.items()}
     _compare_step(env, h, [x], gold, w0, None, 'timing N=4096 B=2')
     assert len(h.metrics_train) == 1
+
+
+def test_training_paths_agree_at_full_width(env, monkeypatch):
+    """The training step's fast forms against its plain ones on the metric shape (timing head, N = 2048: 20 x 516 input,
+    batch of 3): split-fp16 forward convolutions / data gradients (conv_f16x3s_kernel, TRAIN form), the weight gradient
+    without im2col (wgrad_kernel) and the fused BatchNormalization passes (bnf_*) on one side; im2col + f32-MFMA GEMMs +
+    col2im and the generic column reductions on the other (AMT_TRAIN_FAST / AMT_TRAIN_WGRAD / AMT_TRAIN_FUSED_BN = 0,
+    read when a trainer is created).  Same weights, same batch: loss, predictions and every gradient must agree to the
+    bars the oracle comparison uses (the oracle itself needs minutes at this size)."""
+    p = env['hp'].Hyperparams(N=2048)
+    rng = np.random.default_rng(5)
+    x = (rng.random((3, 20, 516, 1)) ** 2).astype(np.float32)
+    gold = rng.uniform(0, 516, 3)
+    res = []
+    for plain in (False, True):
+        for k in ('AMT_TRAIN_FAST', 'AMT_TRAIN_WGRAD', 'AMT_TRAIN_FUSED_BN'):
+            if plain:
+                monkeypatch.setenv(k, '0')
+            else:
+                monkeypatch.delenv(k, raising=False)
+        h = env['heads'].timming_classifier(p, calibrated=False)
+        pred = h.train(x, gold)
+        res.append((h.metrics_train[-1][0], pred, h.gradients()))
+    (l0, p0, g0), (l1, p1, g1) = res
+    assert abs(l0 - l1) <= 2e-5 * max(abs(l1), 1e-3), (l0, l1)
+    assert np.abs(p0 - p1).max() <= 1e-4 * max(np.abs(p1).max(), 1e-6)
+    gmax = max(np.abs(v).max() for v in g1.values())
+    worst = 0.0
+    for k in g1:
+        err = np.abs(g0[k] - g1[k]).max()
+        bar = 3e-4 * np.abs(g1[k]).max() + 1e-6 * gmax
+        worst = max(worst, err / bar)
+        assert err <= bar, (k, err, np.abs(g1[k]).max(), gmax)
+    print('training paths: worst gradient difference / bar = %.3f' % worst)
