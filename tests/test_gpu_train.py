@@ -182,6 +182,9 @@ def test_training_paths_agree_at_full_width(env, monkeypatch):
     worst = 0.0
     for k in g1:
         err = np.abs(g0[k] - g1[k]).max()
+        if np.abs(g1[k]).max() < 1e-4 * gmax:        # structurally zero (a bias in front of a training-mode BN): rounding
+            assert np.abs(g0[k]).max() < 1e-4 * gmax, k      # noise on both sides, as in _compare_step
+            continue
         bar = 3e-4 * np.abs(g1[k]).max() + 1e-6 * gmax
         worst = max(worst, err / bar)
         assert err <= bar, (k, err, np.abs(g1[k]).max(), gmax)
