@@ -72,6 +72,7 @@ PROTOTYPES = {
     'amt_db_to_amplitude': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp]),
     'amt_spectral_flatness': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float, vp, vp]),
     'amt_cqt_slices': (C.c_int, [C.POINTER(CqtArgs), vp]),
+    'amt_cqt_slices_complex': (C.c_int, [C.POINTER(CqtArgs), vp, vp]),
     'amt_cqt_coef': (C.c_int, [vp, vp, C.c_int, vp, vp]),
     'amt_cqt_window_max_workspace': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'amt_cqt_window_max': (C.c_int, [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_size_t, vp]),

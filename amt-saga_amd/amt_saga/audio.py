@@ -253,10 +253,11 @@ def db_to_amplitude(db, ref, F):
     return out
 
 
-def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
+def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None, complex_out=False):
     """slice_C for a batch (util_audio.py:411-434, build-defined CQT):
     wave [B, L] f32 device; src_frame [B, frames] int32; table = cqt_table(..., device) =
-    (phase_inc, length, coef).  Returns [B, n_bins, frames]."""
+    (phase_inc, length, coef).  Returns [B, n_bins, frames]; with complex_out the pair (real, imaginary) of that
+    shape, phase referred to each frame's centre (util_audio.py:428: magnitude_only=False keeps librosa's complex C)."""
     lib = _lib.load()
     B, L = wave.shape
     frames = src_frame.shape[1]
@@ -273,6 +274,10 @@ def cqt_slices(wave, src_frame, table, n_bins, hop, bin0=None, ref=None):
     a.wave_stride = _stride0(wave)
     a.B, a.L, a.hop, a.frames, a.n_bins, a.n_table = B, L, int(hop), frames, int(n_bins), \
         int(table[0].shape[0])
+    if complex_out:
+        out_im = empty((B, n_bins, frames))
+        _lib.check(lib.amt_cqt_slices_complex(C.byref(a), ptr(out_im), stream_ptr()))
+        return out, out_im
     _lib.check(lib.amt_cqt_slices(C.byref(a), stream_ptr()))
     return out
 
@@ -762,11 +767,9 @@ class audio_complete:
     def slice_C(self, start, duration, target_frame_count, magnitude_only=True,
                 bins_per_tone=1, filter_scale=2, highest_note='C8', lowest_note='A0',
                 nbins=None):
-        """util_audio.py:411-434 with the build-defined CQT (oracle/cqt.py);
-        like the reference, `filter_scale` is ignored (:426) and only the
-        magnitude is available (magnitude_only=False is not supported)."""
-        if not magnitude_only:
-            raise NotImplementedError('complex CQT output is not provided')
+        """util_audio.py:411-434 with the build-defined CQT (oracle/cqt.py); like the reference, `filter_scale` is
+        ignored (:426).  magnitude_only=False returns the complex CQT (:428 skips the np.abs), complex64, its phase
+        referred to each frame's centre."""
         if nbins is None:
             nbins = int((note_to_midi(highest_note) - note_to_midi(lowest_note)) * bins_per_tone)
         fmin = float(midi_to_hz(note_to_midi(lowest_note)))
@@ -774,11 +777,14 @@ class audio_complete:
         wf = to_dev(np.asarray(self.wf, dtype=np.float32))[None]
         src = self._resize_index(start, duration, target_frame_count)
         table = cqt_table(self.sr, fmin, nbins, int(12 * bins_per_tone), dev)
-        out = np.zeros((nbins, target_frame_count), dtype=np.float32)
+        out = np.zeros((nbins, target_frame_count), dtype=np.float32 if magnitude_only else np.complex64)
         for c0 in range(0, target_frame_count, 8):
             cols = src[c0:c0 + 8]
-            o = cqt_slices(wf, to_dev(cols[None], torch.int32), table, nbins, self.hl)
-            out[:, c0:c0 + len(cols)] = o[0].cpu().numpy()
+            o = cqt_slices(wf, to_dev(cols[None], torch.int32), table, nbins, self.hl, complex_out=not magnitude_only)
+            if magnitude_only:
+                out[:, c0:c0 + len(cols)] = o[0].cpu().numpy()
+            else:
+                out[:, c0:c0 + len(cols)] = o[0][0].cpu().numpy() + 1j * o[1][0].cpu().numpy()
         return out
 
     @staticmethod

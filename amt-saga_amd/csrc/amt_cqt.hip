@@ -90,6 +90,7 @@ struct CqtBlocksArgs {
     const int *bin0;            // slices mode: [B] first table row of the window, or null
     const float *ref;           // slices mode: [B] divisor or null
     float *out;                 // slices mode: [B][n_bins][frames]
+    float *out_im;              // slices mode, complex form: imaginary parts (out then holds the real parts); null => magnitudes
     int frames, n_bins, n_table;
     float *fg_ws;               // GBUF: [workgroups][blk_cap][12] block sums in HBM (signals too long for the LDS)
     double *pf_ws;              // GBUF: [workgroups][blk_cap + 1][6]
@@ -125,7 +126,10 @@ __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict
             if (t >= 0) { t_min = min(t_min, t); t_max = max(t_max, t); }
         }
         if (kt < 0 || kt >= a.n_table || t_max < 0) {       // uniform: outside the table / an empty slice -> zeros
-            if (tid < a.frames) a.out[((size_t)b * a.n_bins + k) * a.frames + tid] = 0.f;
+            if (tid < a.frames) {
+                a.out[((size_t)b * a.n_bins + k) * a.frames + tid] = 0.f;
+                if (a.out_im) a.out_im[((size_t)b * a.n_bins + k) * a.frames + tid] = 0.f;
+            }
             return;
         }
         t_min = __builtin_amdgcn_readfirstlane(t_min);
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict
     }
     __syncthreads();
     const float scale = 2.0f / sqrtf((float)nk);
+    float fre = 0.f, fim = 0.f;                      // the last frame's complex sum (absolute sample phase), for the complex form
     auto frame = [&](int t) -> float {               // frame t: blocks t .. t+nb-1 whole, the head of block t+nb
         const int i0 = min(max(t - j_lo, 0), nblk), i1 = min(max(t + nb - j_lo, 0), nblk);
         const int jg = t + nb - j_lo;
@@ -285,14 +290,30 @@ __global__ __launch_bounds__(256) void cqt_blocks_kernel(const float *__restrict
         const float br = cd * sfr[4] - sd * sfr[5], bi = cd * sfr[5] + sd * sfr[4];     // e^{+i d} S-
         const float re = 0.5f * sfr[0] - 0.25f * (ar + br);
         const float im = 0.5f * sfr[1] - 0.25f * (ai + bi);
+        fre = re; fim = im;
         return sqrtf(re * re + im * im) * scale;
     };
     if (SLICES) {
         if (tid < a.frames) {
             const int t = a.src_frame[b * a.frames + tid];
             float v = t >= 0 ? frame(t) : 0.f;
-            if (a.ref) v = __fdiv_rn(v, a.ref[b]);
-            a.out[((size_t)b * a.n_bins + k) * a.frames + tid] = v;
+            const size_t oi = ((size_t)b * a.n_bins + k) * a.frames + tid;
+            if (a.out_im) {
+                // complex form: the sums above carry the phase of the ABSOLUTE sample index; the value handed out refers
+                // to the frame's centre t H (the filter's phase is zero there, as for a centred filter bank): e^{+i phi t H},
+                // integer-exact mod 2^32
+                float re = 0.f, im = 0.f;
+                if (t >= 0) {
+                    const float turns = (float)((unsigned int)(t << hshift) * inc) * 2.3283064365386963e-10f;
+                    const float c = __builtin_amdgcn_cosf(turns), sn = __builtin_amdgcn_sinf(turns);
+                    re = (fre * c - fim * sn) * scale; im = (fre * sn + fim * c) * scale;
+                    if (a.ref) { re = __fdiv_rn(re, a.ref[b]); im = __fdiv_rn(im, a.ref[b]); }
+                }
+                a.out[oi] = re; a.out_im[oi] = im;
+            } else {
+                if (a.ref) v = __fdiv_rn(v, a.ref[b]);
+                a.out[oi] = v;
+            }
         }
         return;
     }
@@ -717,13 +738,13 @@ __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
 
 // Fallback for signals whose block sums do not fit the LDS (a whole song handed to slice_C): every requested
 // frame summed directly over its own N_k samples, one workgroup per (bin, window).  Any L; 8 N_k sample visits.
-__global__ __launch_bounds__(256) void cqt_slices_direct_kernel(amt_cqt_args a) {
+__global__ __launch_bounds__(256) void cqt_slices_direct_kernel(amt_cqt_args a, float *out_im) {
     __shared__ float red[4][2];
     const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int kt = (a.bin0 ? a.bin0[b] : 0) + k;
     float *o = a.out + ((size_t)b * a.n_bins + k) * a.frames;
     if (kt < 0 || kt >= a.n_table) {                // uniform
-        if (tid < a.frames) o[tid] = 0.f;
+        if (tid < a.frames) { o[tid] = 0.f; if (out_im) out_im[((size_t)b * a.n_bins + k) * a.frames + tid] = 0.f; }
         return;
     }
     const int nk = a.length[kt];
@@ -752,6 +773,18 @@ __global__ __launch_bounds__(256) void cqt_slices_direct_kernel(amt_cqt_args a) 
         if (tid == 0) {
             const float r = red[0][0] + red[1][0] + red[2][0] + red[3][0];
             const float i = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+            if (out_im) {                                  // complex form, phase referred to the frame centre t hop
+                float cr = 0.f, ci = 0.f;
+                if (t >= 0) {
+                    const float turns = (float)((unsigned int)((long long)t * a.hop) * inc) * 2.3283064365386963e-10f;
+                    const float c = __builtin_amdgcn_cosf(turns), sn = __builtin_amdgcn_sinf(turns);
+                    cr = (r * c - i * sn) * scale; ci = (r * sn + i * c) * scale;
+                    if (a.ref) { cr = __fdiv_rn(cr, a.ref[b]); ci = __fdiv_rn(ci, a.ref[b]); }
+                }
+                o[j] = cr;
+                out_im[((size_t)b * a.n_bins + k) * a.frames + j] = ci;
+                continue;
+            }
             float v = t >= 0 ? sqrtf(r * r + i * i) * scale : 0.f;
             if (a.ref) v = __fdiv_rn(v, a.ref[b]);
             o[j] = v;
@@ -777,7 +810,13 @@ extern "C" int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, in
     return AMT_OK;
 }
 
-extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
+static int cqt_slices_impl(const amt_cqt_args *args, float *out_im, void *stream);
+extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) { return cqt_slices_impl(args, nullptr, stream); }
+extern "C" int amt_cqt_slices_complex(const amt_cqt_args *args, float *out_im, void *stream) {
+    if (!out_im) return AMT_E_INVALID;
+    return cqt_slices_impl(args, out_im, stream);
+}
+static int cqt_slices_impl(const amt_cqt_args *args, float *out_im, void *stream) {
     if (!args || !args->wave || !args->src_frame || !args->phase_inc || !args->length || !args->out)
         return AMT_E_INVALID;
     const amt_cqt_args &q = *args;
@@ -788,7 +827,7 @@ extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
     size_t lds;
     if (cqt_blocks_geometry(q.L, q.hop, &a.hshift, &a.blk_cap, &lds) != AMT_OK) {
         // hop not a power of two in 128..2048, or more hop-blocks than the LDS holds: the direct form
-        cqt_slices_direct_kernel<<<dim3(q.n_bins, q.B), 256, 0, (hipStream_t)stream>>>(q);
+        cqt_slices_direct_kernel<<<dim3(q.n_bins, q.B), 256, 0, (hipStream_t)stream>>>(q, out_im);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
     }
@@ -800,7 +839,7 @@ extern "C" int amt_cqt_slices(const amt_cqt_args *args, void *stream) {
         attr_set = true;
     }
     a.wave_stride = q.wave_stride; a.L = q.L; a.H = q.hop; a.T = 1 + q.L / q.hop;
-    a.src_frame = q.src_frame; a.bin0 = q.bin0; a.ref = q.ref; a.out = q.out;
+    a.src_frame = q.src_frame; a.bin0 = q.bin0; a.ref = q.ref; a.out = q.out; a.out_im = out_im;
     a.frames = q.frames; a.n_bins = q.n_bins; a.n_table = q.n_table;
     cqt_blocks_kernel<true, false><<<dim3(q.n_bins, q.B), 256, lds, (hipStream_t)stream>>>(q.wave, q.phase_inc, q.length,
                                                                                      q.coef, a);

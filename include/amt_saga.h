@@ -182,6 +182,12 @@ typedef struct amt_cqt_args {
  * in LDS); otherwise every frame is summed directly over its own N_k samples (any L and hop, coef unused). */
 int amt_cqt_slices(const amt_cqt_args *args, void *stream);
 
+/* Complex form (util_audio.py:424-429 with magnitude_only=False: librosa.cqt's complex output is returned as is):
+ * args->out receives the real parts, out_im the imaginary parts, both [B][n_bins][frames].  The phase refers to the
+ * frame's centre (sample t * hop), where the analysis filter's own phase is zero -- the convention of a centred filter
+ * bank; like the magnitudes, the values follow the build's CQT definition (oracle/cqt.py), not librosa's recursion. */
+int amt_cqt_slices_complex(const amt_cqt_args *args, float *out_im, void *stream);
+
 /* Per-bin phasor table of a CQT grid (32 x 3 unit complex numbers per bin, f64-evaluated): computed once per
  * (phase_inc, length) table and passed to amt_cqt_slices / amt_cqt_window_max.  coef: [n_table][192] floats. */
 int amt_cqt_coef(const uint32_t *phase_inc, const int32_t *length, int n_table, float *coef, void *stream);

@@ -58,9 +58,14 @@ def cqt_table(sr, fmin_hz, n_bins, bins_per_octave):
     return inc.astype(np.uint32), length.astype(np.int32), freq
 
 
-def cqt_frames(x, frames, phase_inc, length, hop):
+def cqt_frames(x, frames, phase_inc, length, hop, complex_out=False):
     """|C[k, t]| for the listed STFT-frame indices (-1 -> zero column).
     x float [L]; returns float64 [n_bins, len(frames)].
+
+    complex_out (util_audio.py:428, magnitude_only=False: the complex CQT is handed on as librosa returns it): complex128
+    C[k, t] with the phase referred to the frame's CENTRE, sample t * hop -- the analysis filter's own phase is zero there,
+    the convention of a centred filter bank; in the integer oscillator below that is the factor
+    exp(+i phi(t * hop)) on the absolute-phase sum.
 
     The oscillator phase of absolute sample m is (m * inc mod 2^32) / 2^32 turns.
     Because that map is additive mod 2^32, exp(-i phi(a+n)) = exp(-i phi(a)) *
@@ -68,7 +73,7 @@ def cqt_frames(x, frames, phase_inc, length, hop):
     magnitude -- so one basis per bin (relative index n) serves every frame."""
     x = np.asarray(x, dtype=np.float64)
     L = len(x)
-    out = np.zeros((len(length), len(frames)))
+    out = np.zeros((len(length), len(frames)), dtype=np.complex128 if complex_out else np.float64)
     for k in range(len(length)):
         nk = int(length[k])
         inc = int(phase_inc[k])
@@ -84,7 +89,13 @@ def cqt_frames(x, frames, phase_inc, length, hop):
             if hi <= lo:
                 continue
             s = np.dot(x[lo:hi], basis[lo - a:hi - a])
-            out[k, j] = np.abs(s) * 2.0 / np.sqrt(nk)
+            if complex_out:
+                # basis index n carries phi(n); absolute sample a + n carries phi(a) + phi(n): s e^{-i phi(a)} is the
+                # absolute-phase sum, and e^{+i phi(t hop)} refers it to the frame centre -- together e^{+i phi(t hop - a)}
+                rel = ((int(t) * hop - a) * inc) & 0xFFFFFFFF
+                out[k, j] = s * np.exp(1j * rel * (2.0 * np.pi / 2.0 ** 32)) * 2.0 / np.sqrt(nk)
+            else:
+                out[k, j] = np.abs(s) * 2.0 / np.sqrt(nk)
     return out
 
 

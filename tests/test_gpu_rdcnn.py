@@ -361,6 +361,42 @@ def test_cqt_slices_long_signal_and_odd_hop(env):
         assert np.all(out[0][:, 4] == 0)
 
 
+def test_cqt_slices_complex(env):
+    """slice_C(magnitude_only=False) (util_audio.py:424-434): real and imaginary parts of the build's CQT, phase referred
+    to the frame centre, against oracle.cqt.cqt_frames(complex_out=True) -- the block-sum kernel (window-sized signal,
+    hop 512), the direct form (a hop that is no power of two) and the audio_complete method; 1e-4 of the largest |C|."""
+    audio, ocqt, torch = env['audio'], env['ocqt'], env['torch']
+    sr = 44100
+    rng = np.random.default_rng(9)
+    for hop, L in ((512, 66 * 512), (441, 30000)):
+        t = np.arange(L) / sr
+        wave = np.stack([np.sin(2 * np.pi * 330 * t + 0.4) * np.exp(-2 * t) + 0.05 * rng.standard_normal(L),
+                         0.3 * np.sin(2 * np.pi * 98 * t + 1) + 0.2 * np.sin(2 * np.pi * 1244.5 * t)]).astype(np.float32)
+        T = 1 + L // hop
+        inc, length, _ = ocqt.cqt_table(sr, 65.4, 60, 12)
+        table = audio.cqt_table(sr, 65.4, 60, 12, 'cuda')
+        src = np.array([[0, 3, T // 3, T // 2, -1, T - 9, T - 2, T - 1], [5, 6, 7, 8, 9, 10, 11, 12]], np.int32)
+        re, im = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src).cuda(), table, 60, hop,
+                                  complex_out=True)
+        mag = audio.cqt_slices(torch.from_numpy(wave).cuda(), torch.from_numpy(src).cuda(), table, 60, hop).cpu().numpy()
+        got = re.cpu().numpy() + 1j * im.cpu().numpy()
+        for i in range(2):
+            ref = ocqt.cqt_frames(wave[i], src[i], inc, length, hop, complex_out=True)
+            assert np.abs(got[i] - ref).max() <= REL * np.abs(ref).max(), (hop, i, np.abs(got[i] - ref).max(), np.abs(ref).max())
+            assert np.abs(np.abs(got[i]) - mag[i]).max() <= 2e-6 * mag[i].max()
+        assert np.all(got[0][:, 4] == 0)
+    # the method: complex64 [n_bins, target], columns by the tile / crop rule of _resize
+    ac = audio.audio_complete(wave[0].astype(np.float64), 2048, hop_length=512, sample_rate=sr)
+    Cc = ac.slice_C(0.1, 0.3, 12, magnitude_only=False, lowest_note='C3', highest_note='C5')
+    Cm = ac.slice_C(0.1, 0.3, 12, lowest_note='C3', highest_note='C5')
+    assert Cc.dtype == np.complex64 and Cc.shape == Cm.shape == (24, 12)
+    assert np.abs(np.abs(Cc) - Cm).max() <= 2e-6 * Cm.max()
+    inc, length, _ = ocqt.cqt_table(sr, float(440.0 * 2 ** ((48 - 69) / 12)), 24, 12)
+    cols = ac._resize_index(0.1, 0.3, 12)
+    ref = ocqt.cqt_frames(wave[0], cols, inc, length, 512, complex_out=True)
+    assert np.abs(Cc - ref).max() <= REL * np.abs(ref).max()
+
+
 @pytest.mark.parametrize('hop,L,grids', [
     # N_k from 376 (< hop: no whole block) to 53938 (> L); L not a multiple of the hop
     (512, 512 * 40 + 123, ((27.5, 87, 12), (220.0, 60, 48), (2000.0, 24, 24))),

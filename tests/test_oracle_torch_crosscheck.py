@@ -212,6 +212,37 @@ def test_oracle_cqt_known_answers():
     assert C[10, 1] < 0.75 * C[10, 2]                                         # half of the first frame is padding
 
 
+def test_oracle_cqt_complex_known_answers():
+    """Complex form (util_audio.py:428, magnitude_only=False): |C| equals the magnitude form exactly; for a stationary
+    cosine A cos(2 pi f n / sr + ph0) at a bin's quantised centre frequency the value referred to the frame's centre
+    is (sqrt(N_k) A / 2) e^{+i (ph0 + 2 pi f t hop / sr)} -- the signal's own phase at the frame centre -- up to the
+    image term; and it is the direct centred-filter sum sum_n x[t hop - N_k//2 + n] w[n] e^{-2 pi i f (n - N_k//2) / sr}."""
+    from oracle import cqt as ocqt
+    sr, hop, bpo = 44100, 512, 24
+    inc, length, freq = ocqt.cqt_table(sr, 220.0, 48, bpo)
+    L = hop * 120
+    n = np.arange(L)
+    frames = [40, 41, 57, 80, -1]
+    rng = np.random.default_rng(0)
+    noise = rng.standard_normal(L)
+    Cn = ocqt.cqt_frames(noise, frames, inc, length, hop, complex_out=True)
+    assert np.abs(np.abs(Cn) - ocqt.cqt_frames(noise, frames, inc, length, hop)).max() < 1e-12
+    assert np.all(Cn[:, 4] == 0)
+    for k in (5, 20, 40):
+        fq = float(inc[k]) / 2.0 ** 32                                       # cycles per sample, quantised
+        A, ph0 = 0.7, 0.3
+        x = A * np.cos(2 * np.pi * fq * n + ph0)
+        C = ocqt.cqt_frames(x, frames[:4], inc, length, hop, complex_out=True)
+        for j, t in enumerate(frames[:4]):
+            want = np.sqrt(length[k]) * A / 2.0 * np.exp(1j * (ph0 + 2 * np.pi * fq * t * hop))
+            assert abs(C[k, j] - want) / abs(want) < 2e-3, (k, t, C[k, j], want)
+        nk = int(length[k])
+        a = frames[0] * hop - nk // 2
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(nk) / nk)
+        direct = np.sum(noise[a:a + nk] * w * np.exp(-2j * np.pi * fq * (np.arange(nk) - nk // 2))) * 2 / np.sqrt(nk)
+        assert abs(Cn[k, 0] - direct) < 1e-9 * max(abs(direct), 1.0)
+
+
 def test_oracle_cqt_window_max_equals_all_frames():
     """ref_C_* = max of the whole CQT (training.py:271-282).  oracle.cqt.cqt_window_max evaluates it in O(L) per
     bin from cumulative sums; here it is pinned to the definition -- cqt_frames on every frame 0 .. L // hop -- for
