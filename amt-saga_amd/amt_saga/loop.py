@@ -44,7 +44,7 @@ EVENT_FIELDS = ('window', 'iter', 'pitch', 'program', 'velocity', 'onset_frame',
 
 class TranscriptionLoop:
     def __init__(self, params, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True,
-                 groups=(0,), seeds=None, guess='bank'):
+                 groups=(0,), seeds=None, guess='bank', timbres=None):
         self.p = params
         self.heads = tuple(heads)
         self.iters = int(iters)
@@ -53,6 +53,13 @@ class TranscriptionLoop:
         if guess not in ('bank', 'render'):
             raise ValueError('Requested attribute does not exist')
         self.guess = guess
+        # timbres = 'gm' (guess='render' only): every decided MIDI program is synthesised with its own timbre
+        # (synth.gm_timbre_table) instead of one of the three groups
+        if timbres not in (None, 'gm'):
+            raise ValueError("timbres: None or 'gm'")
+        if timbres == 'gm' and guess != 'render':
+            raise ValueError("per-program timbres need guess='render' (the template bank holds the three groups)")
+        self.timbres = timbres
         self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
         # diagnostic hook: when set to a list, iterate() appends one dict per iteration with copies of the heads'
         # pre-rounding outputs (what res_net.predict returns, RDCNN.py:591-597) -- the parity tests compare them
@@ -99,7 +106,8 @@ class TranscriptionLoop:
         for i, g in enumerate(self.groups):
             remap[g] = i
         self.prog_group = to_dev(remap[synth.prog_group_table(p.instrument_classes)], torch.int32)
-        self.prog_preset = to_dev(synth.prog_group_table(p.instrument_classes), torch.int32)
+        self.prog_preset = to_dev(np.arange(p.instrument_classes, dtype=np.int32) if self.timbres == 'gm'
+                                  else synth.prog_group_table(p.instrument_classes), torch.int32)
         self.bank_dur = 1.0
         self.bank_len = int(round((self.bank_dur + synth.TAIL_SECONDS) * sr))
         if bank_waves is None:
@@ -250,7 +258,7 @@ class TranscriptionLoop:
                 _lib.check(self.lib.amt_guess_notes(
                     ptr(program), ptr(pitch), ptr(velocity), ptr(onset), ptr(end), ptr(self.prog_preset),
                     self.prog_preset.shape[0], B, p.H / p.sr, self.bank_dur, 100.0, ptr(notes), st))
-                gw = synth.render_windows_device(notes, self.bank_len, p.sr)
+                gw = synth.render_windows_device(notes, self.bank_len, p.sr, timbres=self.timbres)
                 g = AudioBatch(gw, p.N, p.H).stft(with_phase=False)
                 b.subtract(g.mag, g.ref_max, None, gfr, onset, normalize=True, relu=True)
         if self.trace is not None:

@@ -45,6 +45,44 @@ def prog_group_table(n_prog=112):
     return np.array([program_to_group(p) for p in range(n_prog)], dtype=np.int32)
 
 
+# ---- per-program timbres ------------------------------------------------------------------------------
+# The reference renders every note through the soundfont preset of its MIDI program (util_audio.py:758-786); without a
+# soundfont the build gives each of the 128 General MIDI programs its own additive timbre: the sixteen GM families set
+# (harmonics, spectral slope, decay, attack, even-harmonic weight), the eight programs of a family move slope and decay
+# in steps.  Programs 0, 24 and 40 are exactly the three groups above.  Build-defined, like those.
+GM_FAMILIES = [
+    # H, slope, tau (None = sustained), attack, even      GM programs
+    (12, 1.50, 0.60, 0.002, 1.0),      # 0-7     piano
+    (6, 1.00, 0.25, 0.001, 1.0),       # 8-15    chromatic percussion
+    (9, 0.80, None, 0.010, 1.0),       # 16-23   organ
+    (10, 1.20, 0.35, 0.002, 1.0),      # 24-31   guitar
+    (8, 1.30, 0.50, 0.004, 1.0),       # 32-39   bass
+    (16, 1.00, None, 0.080, 1.0),      # 40-47   strings
+    (14, 1.10, None, 0.120, 1.0),      # 48-55   ensemble
+    (14, 0.90, None, 0.030, 1.0),      # 56-63   brass
+    (12, 1.00, None, 0.020, 0.3),      # 64-71   reed
+    (5, 1.80, None, 0.040, 0.5),       # 72-79   pipe
+    (20, 1.00, None, 0.005, 1.0),      # 80-87   synth lead
+    (10, 1.40, None, 0.250, 1.0),      # 88-95   synth pad
+    (12, 1.20, 1.20, 0.100, 1.0),      # 96-103  synth effects
+    (10, 1.10, 0.30, 0.003, 1.0),      # 104-111 ethnic
+    (6, 0.90, 0.15, 0.001, 1.0),       # 112-119 percussive
+    (8, 1.00, 0.40, 0.010, 1.0),       # 120-127 sound effects
+]
+
+
+def gm_timbre(program):
+    """(H, slope, tau or 0.0 for sustained, attack, even) of General MIDI program 0..127."""
+    H, slope, tau, attack, even = GM_FAMILIES[int(program) // 8]
+    i = int(program) % 8
+    return (H, slope + 0.04 * i, 0.0 if tau is None else tau * (1.0 - 0.05 * i), attack, even)
+
+
+def gm_timbre_table(n_prog=128):
+    """float32 [n_prog, 5]: the table amt_synth_windows_timbres reads (note field 0 = MIDI program)."""
+    return np.array([gm_timbre(p) for p in range(n_prog)], dtype=np.float32)
+
+
 def notes_tensor(notes, max_notes=None):
     """list (per window) of note lists -> float32 [B, max_notes, 5]; unused slots pitch -1."""
     mn = max_notes or max(len(n) for n in notes)
@@ -56,10 +94,14 @@ def notes_tensor(notes, max_notes=None):
     return out
 
 
-def render_windows_device(notes, L, sr=44100, out=None):
+_TIMBRE_DEV = {}
+
+
+def render_windows_device(notes, L, sr=44100, out=None, timbres=None):
     """HIP synthesiser.  notes: list of note lists, or a device float32 [B, M, 5] tensor
     (rows {group, pitch, velocity, onset_s, dur_s}; pitch < 0 = unused).  Returns a device
-    float32 [B, L] tensor."""
+    float32 [B, L] tensor.  timbres: None = field 0 is one of the three groups; 'gm' = field 0 is a General MIDI
+    program rendered with gm_timbre_table(); or a float32 [n, 5] table of the caller's."""
     from . import _lib
     from .device import empty, ptr, stream_ptr, to_dev
     lib = _lib.load()
@@ -70,8 +112,22 @@ def render_windows_device(notes, L, sr=44100, out=None):
     B, M = nt.shape[0], nt.shape[1]
     wave = out if out is not None else empty((B, int(L)))
     peak = empty((B,))
-    _lib.check(lib.amt_synth_windows(ptr(nt), M, B, int(L), float(sr), ptr(wave), wave.stride(0),
-                                     ptr(peak), stream_ptr()))
+    if timbres is None:
+        _lib.check(lib.amt_synth_windows(ptr(nt), M, B, int(L), float(sr), ptr(wave), wave.stride(0),
+                                         ptr(peak), stream_ptr()))
+        return wave
+    if isinstance(timbres, str):
+        if timbres != 'gm':
+            raise ValueError("timbres: None, 'gm' or a [n, 5] table")
+        if 'gm' not in _TIMBRE_DEV:
+            _TIMBRE_DEV['gm'] = to_dev(gm_timbre_table())
+        tb = _TIMBRE_DEV['gm']
+    else:
+        tb = timbres if isinstance(timbres, torch.Tensor) else to_dev(np.ascontiguousarray(timbres, dtype=np.float32))
+    if tb.dim() != 2 or tb.shape[1] != 5 or tb.dtype != torch.float32 or not tb.is_contiguous():
+        raise ValueError('timbre table must be float32 [n, 5]')
+    _lib.check(lib.amt_synth_windows_timbres(ptr(nt), M, B, int(L), float(sr), ptr(tb), int(tb.shape[0]), ptr(wave),
+                                             wave.stride(0), ptr(peak), stream_ptr()))
     return wave
 
 

@@ -12,18 +12,22 @@
 // the loop's "render" guess mode, one guess per window and iteration.
 #include "amt_common.h"
 
-struct Preset { int H; float slope, tau, attack; };
+// timbre = {H, slope, tau (0 = sustain), attack, even}: harmonic h weighs h^-slope, times `even` when h is even
+// (reeds and stopped pipes are weak there).  The three built-in groups, or a caller's table (amt_synth_windows_timbres:
+// one row per General MIDI program, amt_saga/synth.py:gm_timbre_table).
+struct Preset { int H; float slope, tau, attack, even; };
 __constant__ Preset c_presets[3] = {
-    {12, 1.5f, 0.6f, 0.002f},      // piano
-    {16, 1.0f, 0.0f, 0.08f},       // strings (tau 0 = sustain)
-    {10, 1.2f, 0.35f, 0.002f},     // guitar
+    {12, 1.5f, 0.6f, 0.002f, 1.0f},      // piano
+    {16, 1.0f, 0.0f, 0.08f, 1.0f},       // strings (tau 0 = sustain)
+    {10, 1.2f, 0.35f, 0.002f, 1.0f},     // guitar
 };
 #define SYN_RELEASE_TAU 0.06f
 #define SYN_TAIL 1.0f
 
 __global__ __launch_bounds__(256) void synth_kernel(const float *__restrict__ notes, int max_notes,
                                                      float *__restrict__ wave, size_t wave_stride, int L,
-                                                     float sr, float *__restrict__ peak) {
+                                                     float sr, float *__restrict__ peak,
+                                                     const float *__restrict__ timbres, int n_timbres) {
     __shared__ float red[16];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -34,11 +38,17 @@ __global__ __launch_bounds__(256) void synth_kernel(const float *__restrict__ no
         for (int n = 0; n < max_notes; ++n) {
             const float pitch = nt[n * 5 + 1];
             if (pitch < 0.f) continue;
-            const int g = min(max((int)nt[n * 5 + 0], 0), 2);
+            const int g = min(max((int)nt[n * 5 + 0], 0), timbres ? n_timbres - 1 : 2);
             const float vel = nt[n * 5 + 2], onset = nt[n * 5 + 3], dur = nt[n * 5 + 4];
             const double tt = t - (double)onset;
             if (tt < 0.0 || tt >= (double)dur + (double)SYN_TAIL) continue;
-            const Preset pr = c_presets[g];
+            Preset pr;
+            if (timbres) {
+                const float *tb = timbres + (size_t)g * 5;
+                pr.H = (int)tb[0]; pr.slope = tb[1]; pr.tau = tb[2]; pr.attack = tb[3]; pr.even = tb[4];
+            } else {
+                pr = c_presets[g];
+            }
             const float ttf = (float)tt;
             float env = fminf(ttf / pr.attack, 1.0f);
             if (pr.tau > 0.f) env *= expf(-ttf / pr.tau);
@@ -49,7 +59,8 @@ __global__ __launch_bounds__(256) void synth_kernel(const float *__restrict__ no
                 if ((double)h * f0 >= 0.5 * (double)sr) break;
                 double ph = (double)h * f0 * tt;
                 ph -= floor(ph);
-                y += powf((float)h, -pr.slope) * __builtin_amdgcn_sinf((float)ph);
+                const float wgt = powf((float)h, -pr.slope) * ((h & 1) ? 1.0f : pr.even);
+                y += wgt * __builtin_amdgcn_sinf((float)ph);
             }
             const float a = vel * (1.0f / 128.0f);
             acc += (a * a) * (a * a) * y * env;
@@ -98,20 +109,27 @@ __global__ void guess_notes_kernel(const int32_t *__restrict__ program, const in
 
 extern "C" {
 
-int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate, float *wave,
-                      size_t wave_stride, float *peak_scratch, void *stream) {
+int amt_synth_windows_timbres(const float *notes, int max_notes, int B, int L, float sample_rate,
+                              const float *timbres, int n_timbres, float *wave, size_t wave_stride,
+                              float *peak_scratch, void *stream) {
     if (!notes || !wave || !peak_scratch || B <= 0 || L <= 0 || max_notes <= 0 || sample_rate <= 0)
         return AMT_E_INVALID;
+    if (timbres && n_timbres <= 0) return AMT_E_INVALID;
     if (wave_stride < (size_t)L) return AMT_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     AMT_HIP_CHECK(hipMemsetAsync(peak_scratch, 0, sizeof(float) * B, st));
     dim3 grid((L + 255) / 256, B);
-    synth_kernel<<<grid, 256, 0, st>>>(notes, max_notes, wave, wave_stride, L, sample_rate, peak_scratch);
+    synth_kernel<<<grid, 256, 0, st>>>(notes, max_notes, wave, wave_stride, L, sample_rate, peak_scratch, timbres, n_timbres);
     int gx = (L + 255) / 256;
     if (gx > 64) gx = 64;
     synth_scale_kernel<<<dim3(gx, B), 256, 0, st>>>(notes, max_notes, wave, wave_stride, L, peak_scratch);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
+}
+
+int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate, float *wave,
+                      size_t wave_stride, float *peak_scratch, void *stream) {
+    return amt_synth_windows_timbres(notes, max_notes, B, L, sample_rate, nullptr, 0, wave, wave_stride, peak_scratch, stream);
 }
 
 int amt_guess_notes(const int32_t *program, const int32_t *pitch, const int32_t *velocity,

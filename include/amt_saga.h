@@ -244,6 +244,14 @@ int amt_affine_i32(const int32_t *x, int n, int mul, int add, int32_t *out, void
  * peak_scratch [B] f32 device scratch. */
 int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate,
                       float *wave, size_t wave_stride, float *peak_scratch, void *stream);
+/* Per-program timbres ("per-program timbres"; util_audio.py:758-786 renders every MIDI program through
+ * its own soundfont preset): notes[..][0] indexes a caller-supplied table timbres [n_timbres][5] f32 (device) =
+ * {harmonics H, spectral slope, decay tau s (0 = sustained), attack s, weight of the even harmonics}; the build's
+ * table for the 128 General MIDI programs is amt_saga/synth.py:gm_timbre_table.  timbres == NULL: the three built-in
+ * groups of amt_synth_windows. */
+int amt_synth_windows_timbres(const float *notes, int max_notes, int B, int L, float sample_rate,
+                              const float *timbres, int n_timbres, float *wave, size_t wave_stride,
+                              float *peak_scratch, void *stream);
 /* one guess note per window from the loop's integer decisions:
  * {prog_group[program], pitch, velocity (or default), 0, min((end-onset)*frame_seconds, max_dur)}
  * (training.py:421-424 builds the guessed note the same way, from the gold values) */

@@ -46,6 +46,40 @@ def test_synth_kernel_vs_cpu_definition(env):
     assert torch.equal(a, synth.render_windows_device(notes, L, sr))
 
 
+def test_synth_gm_program_timbres_vs_cpu_definition(env):
+    """Per-program timbres: every General MIDI program 0..127 through amt_synth_windows_timbres with the
+    build's table against the float64 restatement; mixtures of programs in one window; programs 0 / 24 / 40 equal the
+    three built-in groups bit for bit; a caller's own table."""
+    synth, torch = env['synth'], env['torch']
+    sr, L = 44100, 44100 + 300
+    singles = [[(pr, 45 + (pr * 7) % 40, 40 + (pr * 5) % 80, 0.05, 0.4)] for pr in range(128)]
+    rng = np.random.default_rng(3)
+    mixes = [[(int(rng.integers(0, 128)), int(rng.integers(30, 100)), int(rng.integers(20, 127)),
+               float(rng.uniform(0, 0.5)), float(rng.uniform(0.1, 0.6))) for _ in range(n)] for n in (2, 3, 6)]
+    notes = singles + mixes
+    got = synth.render_windows_device(notes, L, sr, timbres='gm').cpu().numpy()
+    distinct = set()
+    for i, ns in enumerate(notes):
+        want = osynth.render_window(ns, L, sr, timbres='gm').numpy()
+        peak = np.abs(want).max()
+        assert peak > 0 and np.abs(got[i] - want).max() / peak < 2e-5, i
+        if i < 128:
+            distinct.add(tuple(np.round(synth.gm_timbre_table()[i], 6)))
+    assert len(distinct) == 128                                   # no two programs share a timbre
+    for prog, grp in ((0, 0), (24, 2), (40, 1)):
+        a = synth.render_windows_device([[(prog, 60, 90, 0.1, 0.5)]], L, sr, timbres='gm')
+        b = synth.render_windows_device([[(grp, 60, 90, 0.1, 0.5)]], L, sr)
+        assert torch.equal(a, b), prog
+    own = np.array([[3, 2.0, 0.0, 0.01, 0.0]], np.float32)         # three harmonics, the even one silent
+    w = synth.render_windows_device([[(0, 69, 100, 0.0, 0.5)]], L, sr, timbres=own).cpu().numpy()[0]
+    spec = np.abs(np.fft.rfft(w[:22050] * np.hanning(22050)))
+    f = np.fft.rfftfreq(22050, 1 / sr)
+    pk = lambda hz: spec[np.abs(f - hz) < 6].max()
+    assert pk(880.0) < 1e-3 * pk(440.0) and pk(1320.0) > 0.05 * pk(440.0)
+    with pytest.raises(ValueError):
+        synth.render_windows_device(singles[:1], L, sr, timbres=np.zeros((2, 4), np.float32))
+
+
 def test_synth_argument_checks(env):
     from amt_saga import _lib
     lib = _lib.load()
@@ -58,16 +92,17 @@ def test_synth_argument_checks(env):
                                  None) == _lib.AMT_E_SHAPE
 
 
-@pytest.mark.parametrize('heads,iters,seeds', [
-    (('timing', 'pitch', 'velocity'), 2, None),
-    (('timing', 'pitch', 'instrument', 'velocity'), 2, None),
+@pytest.mark.parametrize('heads,iters,seeds,timbres', [
+    (('timing', 'pitch', 'velocity'), 2, None, None),
+    (('timing', 'pitch', 'instrument', 'velocity'), 2, None, None),
+    (('timing', 'pitch', 'instrument', 'velocity'), 2, None, 'gm'),     # every decided program with its own timbre
 ])
-def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
+def test_loop_render_guess_vs_oracle(env, heads, iters, seeds, timbres):
     torch, synth = env['torch'], env['synth']
     p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
     groups = (0, 1, 2) if 'instrument' in heads else (0,)
     lp = env['loop'].TranscriptionLoop(p, heads=heads, iters=iters, groups=groups, seeds=seeds,
-                                       guess='render').setup_device()
+                                       guess='render', timbres=timbres).setup_device()
     L = p.H * (p.timing_frames - 1)
     B = 6
     wave, _ = synth.make_windows(B, L, seed=22, notes_per_window=(1, 3), groups=groups,
@@ -82,7 +117,8 @@ def test_loop_render_guess_vs_oracle(env, heads, iters, seeds):
     def guess_fn(program, pitch, velocity, frames):
         dur = min(float(np.float32(frames) * np.float32(p.H / p.sr)), 1.0)
         vel = velocity if velocity > 0 else 100
-        return osynth.render_window([(int(table[program]), pitch, vel, 0.0, dur)], Lg, p.sr).numpy()
+        g = int(program) if timbres == 'gm' else int(table[program])
+        return osynth.render_window([(g, pitch, vel, 0.0, dur)], Lg, p.sr, timbres=timbres).numpy()
 
     orc = env['oloop'].LoopOracle(p, heads, {k: n.weights for k, n in lp.nets.items()}, iters=iters,
                                   guess_fn=guess_fn)
