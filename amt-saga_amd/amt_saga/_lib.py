@@ -87,6 +87,8 @@ PROTOTYPES = {
     'amt_pack_events': (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     'amt_affine_i32': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'amt_synth_windows': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_size_t, vp, vp]),
+    'amt_sf2_synth_windows': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp,
+                                        C.c_size_t, vp, vp]),
     'amt_synth_windows_timbres': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_size_t, vp, vp]),
     'amt_guess_notes': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                   C.c_float, vp, vp]),

@@ -44,7 +44,7 @@ EVENT_FIELDS = ('window', 'iter', 'pitch', 'program', 'velocity', 'onset_frame',
 
 class TranscriptionLoop:
     def __init__(self, params, heads=('timing', 'pitch', 'velocity'), iters=1, subtract=True,
-                 groups=(0,), seeds=None, guess='bank', timbres=None):
+                 groups=(0,), seeds=None, guess='bank', timbres=None, soundfont=None):
         self.p = params
         self.heads = tuple(heads)
         self.iters = int(iters)
@@ -60,6 +60,14 @@ class TranscriptionLoop:
         if timbres == 'gm' and guess != 'render':
             raise ValueError("per-program timbres need guess='render' (the template bank holds the three groups)")
         self.timbres = timbres
+        # soundfont (guess='render' only): an sf2.SoundFont or a path -- the guess is played from its samples
+        # (main.py:25-29 -soundfont_path; util_audio.py:758-786), every decided MIDI program through its own preset
+        if soundfont is not None and guess != 'render':
+            raise ValueError("a soundfont needs guess='render'")
+        if soundfont is not None and not hasattr(soundfont, 'programs'):
+            from . import sf2 as _sf2
+            soundfont = _sf2.SoundFont(soundfont)
+        self.soundfont = soundfont
         self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
         # diagnostic hook: when set to a list, iterate() appends one dict per iteration with copies of the heads'
         # pre-rounding outputs (what res_net.predict returns, RDCNN.py:591-597) -- the parity tests compare them
@@ -106,7 +114,8 @@ class TranscriptionLoop:
         for i, g in enumerate(self.groups):
             remap[g] = i
         self.prog_group = to_dev(remap[synth.prog_group_table(p.instrument_classes)], torch.int32)
-        self.prog_preset = to_dev(np.arange(p.instrument_classes, dtype=np.int32) if self.timbres == 'gm'
+        self.prog_preset = to_dev(np.arange(p.instrument_classes, dtype=np.int32)
+                                  if (self.timbres == 'gm' or self.soundfont is not None)
                                   else synth.prog_group_table(p.instrument_classes), torch.int32)
         self.bank_dur = 1.0
         self.bank_len = int(round((self.bank_dur + synth.TAIL_SECONDS) * sr))
@@ -258,7 +267,11 @@ class TranscriptionLoop:
                 _lib.check(self.lib.amt_guess_notes(
                     ptr(program), ptr(pitch), ptr(velocity), ptr(onset), ptr(end), ptr(self.prog_preset),
                     self.prog_preset.shape[0], B, p.H / p.sr, self.bank_dur, 100.0, ptr(notes), st))
-                gw = synth.render_windows_device(notes, self.bank_len, p.sr, timbres=self.timbres)
+                if self.soundfont is not None:
+                    from . import sf2 as _sf2
+                    gw = _sf2.render_windows_device(notes, self.bank_len, self.soundfont, p.sr)
+                else:
+                    gw = synth.render_windows_device(notes, self.bank_len, p.sr, timbres=self.timbres)
                 g = AudioBatch(gw, p.N, p.H).stft(with_phase=False)
                 b.subtract(g.mag, g.ref_max, None, gfr, onset, normalize=True, relu=True)
         if self.trace is not None:

@@ -71,6 +71,85 @@ __global__ __launch_bounds__(256) void synth_kernel(const float *__restrict__ no
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(peak) + b, __float_as_int(m));
 }
 
+
+// ---- SoundFont 2 sample playback (amt_saga/sf2.py states the definition; oracle/sf2.py is its float64 checker) ----------
+// zones [nz][20] f32: key lo, hi, velocity lo, hi, start, end, loop start, loop end (frames in the pool), looped,
+// sample rate, root key, scaleTuning (cents / key), tuning (cents), gain, delay, attack, hold, decay (s), sustain (dB),
+// release (s).  first [n_prog + 1]: program p plays zones first[p] .. first[p + 1] - 1.  One thread per output sample.
+#define SF2_ZF 20
+__device__ __forceinline__ float sf2_held_amp(float t, const float *z) {       // envelope while the key is down
+    const float ta = t - z[14];
+    if (ta < 0.f) return 0.f;
+    if (ta < z[15]) return ta / z[15];
+    const float td = ta - z[15] - z[16];
+    if (td <= 0.f) return 1.0f;
+    const float db = fminf(100.0f * td / z[17], z[18]);
+    return exp10f(-db * 0.05f);
+}
+__global__ __launch_bounds__(256) void sf2_synth_kernel(const float *__restrict__ notes, int max_notes,
+                                                         const float *__restrict__ samples,
+                                                         const float *__restrict__ zones,
+                                                         const int32_t *__restrict__ first, int n_prog,
+                                                         float *__restrict__ wave, size_t wave_stride, int L, float sr,
+                                                         float *__restrict__ peak) {
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *nt = notes + (size_t)b * max_notes * 5;
+    float acc = 0.f;
+    if (i < L) {
+        const double t = (double)i / (double)sr;
+        for (int n = 0; n < max_notes; ++n) {
+            const float pitch = nt[n * 5 + 1];
+            if (pitch < 0.f) continue;
+            const int prog = min(max((int)nt[n * 5 + 0], 0), n_prog - 1);
+            const float vel = nt[n * 5 + 2], onset = nt[n * 5 + 3], dur = nt[n * 5 + 4];
+            const double tt = t - (double)onset;
+            if (tt < 0.0 || tt >= (double)dur + (double)SYN_TAIL) continue;
+            const float ttf = (float)tt;
+            const int key = (int)pitch, iv = (int)vel;
+            float y = 0.f;
+            for (int q = first[prog]; q < first[prog + 1]; ++q) {
+                const float *z = zones + (size_t)q * SF2_ZF;
+                if (key < (int)z[0] || key > (int)z[1] || iv < (int)z[2] || iv > (int)z[3]) continue;
+                // volume envelope
+                float amp;
+                if (ttf < dur) amp = sf2_held_amp(ttf, z);
+                else {
+                    const float a0 = sf2_held_amp(dur, z);
+                    if (a0 <= 1e-5f) continue;
+                    const float db = -20.0f * log10f(a0) + 100.0f * (ttf - dur) / z[19];
+                    if (db >= 100.0f) continue;
+                    amp = exp10f(-db * 0.05f);
+                }
+                if (amp <= 0.f) continue;
+                // playback position
+                const double cents = ((double)pitch - (double)z[10]) * (double)z[11] + (double)z[12];
+                const double ratio = exp2(cents / 1200.0) * (double)z[9] / (double)sr;
+                double pos = (double)z[4] + tt * (double)sr * ratio;
+                const double le = (double)z[7], ls = (double)z[6], en = (double)z[5];
+                const bool loop = z[8] != 0.f;
+                if (loop) { if (pos >= le) pos = ls + fmod(pos - ls, le - ls); }
+                else if (pos >= en) continue;
+                const double fl = floor(pos);
+                const long long i0 = (long long)fl;
+                long long i1 = i0 + 1;
+                const float fr = (float)(pos - fl);
+                const float s0 = samples[i0];
+                float s1;
+                if (loop) { if (i1 >= (long long)le) i1 = (long long)ls; s1 = samples[i1]; }
+                else s1 = i1 < (long long)en ? samples[i1] : 0.f;
+                y += (s0 + fr * (s1 - s0)) * (z[13] * amp);
+            }
+            const float a = vel * (1.0f / 128.0f);
+            acc += (a * a) * (a * a) * y;
+        }
+        wave[(size_t)b * wave_stride + i] = acc;
+    }
+    float m = block_max(fabsf(acc), red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int *>(peak) + b, __float_as_int(m));
+}
+
 __global__ __launch_bounds__(256) void synth_scale_kernel(const float *__restrict__ notes, int max_notes,
                                                            float *__restrict__ wave, size_t wave_stride, int L,
                                                            const float *__restrict__ peak) {
@@ -130,6 +209,24 @@ int amt_synth_windows_timbres(const float *notes, int max_notes, int B, int L, f
 int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate, float *wave,
                       size_t wave_stride, float *peak_scratch, void *stream) {
     return amt_synth_windows_timbres(notes, max_notes, B, L, sample_rate, nullptr, 0, wave, wave_stride, peak_scratch, stream);
+}
+
+int amt_sf2_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate, const float *samples,
+                          int n_samples, const float *zones, int n_zones, const int32_t *first, int n_prog, float *wave,
+                          size_t wave_stride, float *peak_scratch, void *stream) {
+    if (!notes || !wave || !peak_scratch || !samples || !zones || !first) return AMT_E_INVALID;
+    if (B <= 0 || L <= 0 || max_notes <= 0 || sample_rate <= 0 || n_samples <= 0 || n_zones <= 0 || n_prog <= 0)
+        return AMT_E_INVALID;
+    if (wave_stride < (size_t)L) return AMT_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    AMT_HIP_CHECK(hipMemsetAsync(peak_scratch, 0, sizeof(float) * B, st));
+    sf2_synth_kernel<<<dim3((L + 255) / 256, B), 256, 0, st>>>(notes, max_notes, samples, zones, first, n_prog, wave,
+                                                               wave_stride, L, sample_rate, peak_scratch);
+    int gx = (L + 255) / 256;
+    if (gx > 64) gx = 64;
+    synth_scale_kernel<<<dim3(gx, B), 256, 0, st>>>(notes, max_notes, wave, wave_stride, L, peak_scratch);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
 }
 
 int amt_guess_notes(const int32_t *program, const int32_t *pitch, const int32_t *velocity,

@@ -252,6 +252,15 @@ int amt_synth_windows(const float *notes, int max_notes, int B, int L, float sam
 int amt_synth_windows_timbres(const float *notes, int max_notes, int B, int L, float sample_rate,
                               const float *timbres, int n_timbres, float *wave, size_t wave_stride,
                               float *peak_scratch, void *stream);
+/* SoundFont 2 sample playback ("optionally SF2 sample playback if a soundfont is supplied";
+ * util_audio.py:758-786 renders through fluidsynth + main.py's -soundfont_path): notes[..][0] is the MIDI program;
+ * samples [n_samples] f32 = the font's 16-bit pool / 32768; zones [n_zones][20] f32 and first [n_prog + 1] i32 as
+ * amt_saga/sf2.py:SoundFont.tables() lays them out (flattened preset x instrument zones of bank 0: ranges, sample
+ * and loop points, tuning, attenuation, volume envelope).  Same amplitude law and 1 s tail as amt_synth_windows.
+ * The zone table is trusted (the host parser validates offsets against the pool). */
+int amt_sf2_synth_windows(const float *notes, int max_notes, int B, int L, float sample_rate, const float *samples,
+                          int n_samples, const float *zones, int n_zones, const int32_t *first, int n_prog,
+                          float *wave, size_t wave_stride, float *peak_scratch, void *stream);
 /* one guess note per window from the loop's integer decisions:
  * {prog_group[program], pitch, velocity (or default), 0, min((end-onset)*frame_seconds, max_dur)}
  * (training.py:421-424 builds the guessed note the same way, from the gold values) */

@@ -80,6 +80,44 @@ def test_synth_gm_program_timbres_vs_cpu_definition(env):
         synth.render_windows_device(singles[:1], L, sr, timbres=np.zeros((2, 4), np.float32))
 
 
+def test_sf2_playback_kernel_vs_cpu_definition(env):
+    """SoundFont 2 sample playback (optional soundfont path): amt_sf2_synth_windows on the font written by
+    tests/sf2_fixture.py against oracle/sf2.py -- looped and one-shot samples, key and velocity splits, layered zones
+    with a preset-level transposition, envelopes, notes outside every zone, mixtures; and the loop's render mode
+    playing its guesses from the font."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sf2_fixture
+    from amt_saga import sf2
+    from oracle import sf2 as osf2
+    torch = env['torch']
+    font = sf2.SoundFont(sf2_fixture.build())
+    sr, L = 44100, 2 * 44100 + 123
+    notes = [[(0, 81, 100, 0.0, 1.5)], [(0, 60, 64, 0.25, 0.3)], [(24, 57, 90, 0.0, 1.2)], [(24, 45, 120, 0.1, 0.5)],
+             [(40, 64, 80, 0.05, 0.6)], [(40, 90, 127, 0.0, 0.4)], [(100, 20, 90, 0.0, 0.2), (7, 60, 90, 0.0, 0.2)],
+             [(0, 72, 50, 0.3, 0.2), (24, 69, 101, 0.0, 0.7), (40, 73, 110, 0.5, 1.0)]]
+    got = sf2.render_windows_device(notes, L, font, sr).cpu().numpy()
+    for i, ns in enumerate(notes):
+        want = osf2.render_window(ns, L, font.samples, font.programs, sr)
+        peak = np.abs(want).max()
+        if i == 6:
+            assert peak == 0 and np.all(got[i] == 0)               # programs the font has no preset for
+            continue
+        assert peak > 0 and np.abs(got[i] - want).max() / peak < 5e-5, (i, np.abs(got[i] - want).max() / peak)
+    a = sf2.render_windows_device(notes, L, font, sr)
+    assert torch.equal(a, sf2.render_windows_device(notes, L, font, sr))
+    # the loop plays its guesses from the font (programs without a preset are silent guesses: nothing is subtracted)
+    p = env['hp'].Hyperparams(N=2048, window_size_note_time=1)
+    lp = env['loop'].TranscriptionLoop(p, heads=('timing', 'pitch', 'velocity'), iters=1, guess='render',
+                                       soundfont=font).setup_device()
+    wave, _ = env['synth'].make_windows(4, p.H * (p.timing_frames - 1), seed=3, notes_per_window=(1, 2), max_onset=0.4,
+                                        device='cuda')
+    events, b = lp.run(wave)
+    assert events.shape[1] == 4 and torch.isfinite(b.mag).all()
+    with pytest.raises(ValueError):
+        env['loop'].TranscriptionLoop(p, guess='bank', soundfont=font)
+
+
 def test_synth_argument_checks(env):
     from amt_saga import _lib
     lib = _lib.load()
