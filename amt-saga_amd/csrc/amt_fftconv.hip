@@ -110,18 +110,22 @@ template <typename T> __device__ __forceinline__ T &fc_at(void *base, unsigned i
 // kernel is bound by memory latency and needs two rows in flight per CU, but two SEPARATE 6-wave workgroups of 168
 // registers do not fit a CU's SIMDs together (2 + 2 waves on one SIMD > 3) -- measured: one resident, 66 % of the wave
 // cycles waiting -- while twelve waves of ONE workgroup spread three per SIMD.
-template <bool IN_FREQ>
-__global__ __launch_bounds__(2 * FC_THREADS, 3) void fc_row_kernel(FcRowArgs a) {
+// ROWS = 1 (default since the registers fit: 128, no spills): one row per 384-thread workgroup, so that TWO such
+// workgroups share a CU (4 + 4 + 2 + 2 waves fit four per SIMD at <= 128 registers; 2 x 78.8 KB of LDS) and run their
+// phases independently of each other instead of meeting at every barrier: 2.21 against 2.46 ms per chained layer of
+// 1024 windows on the same box.  ROWS = 2 (AMT_FC_ROWS=2) is the earlier 768-thread form described above.
+template <bool IN_FREQ, int ROWS = 2>
+__global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_kernel(FcRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fc_smem[];
-    const int half = threadIdx.x >= FC_THREADS ? 1 : 0;
+    const int half = (ROWS == 2 && threadIdx.x >= FC_THREADS) ? 1 : 0;
     const int tid = threadIdx.x - half * FC_THREADS;
     float *buf = fc_smem + (size_t)half * 16 * FC_PS;       // [16][FC_PS] per half
-    float2 *tw = reinterpret_cast<float2 *>(fc_smem + 2 * 16 * FC_PS);
+    float2 *tw = reinterpret_cast<float2 *>(fc_smem + ROWS * 16 * FC_PS);
     const int c16 = (tid >> 2) & 15;                        // channel pair
     const int j24 = (tid & 3) + 4 * (tid >> 6);             // 0 .. 23
-    const int row = min(2 * (int)blockIdx.x + half, a.B * a.H - 1);     // (an odd row count: the last row is done twice)
+    const int row = min(ROWS * (int)blockIdx.x + half, a.B * a.H - 1);     // (an odd row count: the last row is done twice)
     const int b = row / a.H, h = row - b * a.H;
-    for (int i = threadIdx.x; i < FC_NF; i += 2 * FC_THREADS) tw[i] = a.tw[i];
+    for (int i = threadIdx.x; i < FC_NF; i += ROWS * FC_THREADS) tw[i] = a.tw[i];
     float2 x[24];
     if (IN_FREQ) {
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
@@ -545,6 +549,28 @@ static void fc_strides(int H, int *sf, int *sh) {
 }
 
 static const size_t FC_ROW_LDS = (size_t)(2 * 16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+static const size_t FC_ROW_LDS1 = (size_t)(16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+static int fc_rows_per_wg() {
+    static int r = 0;
+    if (!r) { const char *e = getenv("AMT_FC_ROWS"); r = (e && atoi(e) == 2) ? 2 : 1; }
+    return r;
+}
+template <bool IN_FREQ>
+static int fc_row_launch(const FcRowArgs &a, hipStream_t st) {
+    const int rows = a.B * a.H;
+    if (fc_rows_per_wg() == 1) {
+        static bool attr1 = false;
+        if (!attr1) {
+            AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS1));
+            attr1 = true;
+        }
+        fc_row_kernel<IN_FREQ, 1><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
+    } else {
+        fc_row_kernel<IN_FREQ, 2><<<(rows + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
+    }
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
 // persistent row kernels: `per_cu` workgroups per CU (what their registers / LDS allow)
 static int fc_row_grid(int per_cu) {
     static int cus = 0;
@@ -560,17 +586,15 @@ int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size
     if (!L || !in_sp || !Xf || !amaxf || W + 15 > FC_NF) return AMT_E_INVALID;
     static bool attr = false;
     if (!attr) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
         attr = true;
     }
     AMT_HIP_CHECK(hipMemsetAsync(amaxf, 0, (size_t)B * sizeof(float), st));
     FcRowArgs a{};
     a.in_sp = in_sp; a.in_stride = in_stride; a.Xf = Xf; a.amaxf = amaxf; a.tw = L->tw; a.B = B; a.H = H; a.W = W;
     fc_strides(H, &a.sf, &a.sh);
-    fc_row_kernel<false><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
+    return fc_row_launch<false>(a, st);
 }
 
 int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *amaxf, int B, int H, float *Yf, hipStream_t st) {
@@ -606,9 +630,7 @@ int amt_fftconv_inverse_epilogue(const amt_fftconv_layer *L, const float *Yf, co
     a.sc1 = ep.sc1; a.sc1_stride = ep.sc1_stride; a.sc1_w = ep.sc1_w; a.sc1_s = ep.sc1_s; a.sc1_t = ep.sc1_t;
     a.tw = L->tw; a.B = B; a.H = H; a.W = W;
     fc_strides(H, &a.sf, &a.sh);
-    fc_row_kernel<true><<<(B * H + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
+    return fc_row_launch<true>(a, st);
 }
 
 // ---- stand-alone C ABI entry (tests / microbenchmarks): one layer, spatial in, spatial out --------------------------
