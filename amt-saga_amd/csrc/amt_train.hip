@@ -774,6 +774,7 @@ struct amt_trainer {
     size_t arena_cap = 0, arena_used = 0;
     float *red2 = nullptr;                        // column sums of dz per workgroup (bias gradient of the convolution in front)
     size_t red_cap = 0;
+    size_t fast_min_m = 2048;                     // AMT_TRAIN_FAST_MIN_M at create: fewest output positions (B H W) for the fast forms
     bool wgrad_direct_on = true;                  // AMT_TRAIN_WGRAD=0 at create: weight gradients through im2col + GEMM
     int colsum_of = -1;                           // tensor whose gradient's column partials red2 holds (-1: none)
     int colsum_nwg = 0;
@@ -1017,6 +1018,8 @@ int amt_trainer_create(amt_trainer **out, const amt_rdcnn_desc *desc, const floa
     {
         const char *e = getenv("AMT_TRAIN_WGRAD");
         t->wgrad_direct_on = !(e && atoi(e) == 0);
+        const char *m = getenv("AMT_TRAIN_FAST_MIN_M");
+        if (m && atol(m) >= 0) t->fast_min_m = (size_t)atol(m);
     }
     // BatchNormalizations on the fused passes, with the sigmoid behind them folded in (AMT_TRAIN_FUSED_BN=0: the generic
     // column-reduction kernels)
@@ -1186,7 +1189,7 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
     }
     // layers too small to fill the chip stay on the GEMM path (a handful of workgroups walking the whole contraction
     // one after the other is slower than the split-K GEMM)
-    auto fast_now = [&](const Op &o) { return o.job >= 0 && (size_t)B * o.H * o.W >= 2048; };
+    auto fast_now = [&](const Op &o) { return o.job >= 0 && (size_t)B * o.H * o.W >= t->fast_min_m; };
     // AMT_TRAIN_TRACE=1: synchronise and report after every op (locating a faulting kernel)
     static const bool trace = getenv("AMT_TRAIN_TRACE") != nullptr;
     int op_no = 0;
@@ -1396,7 +1399,7 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
             const size_t M = (size_t)B * o.H * o.W;
             const int Kc = o.kh * o.kw * o.Cin;
             const bool one = o.kh == 1 && o.kw == 1;
-            if (t->wgrad_direct_on && wgrad_direct_ok(o) && M >= 2048) {
+            if (t->wgrad_direct_on && wgrad_direct_ok(o) && M >= t->fast_min_m) {
                 rc = wgrad_direct(t, o, in.v, gout, t->params[o.p0].g, B, st);
             } else {
                 const float *A = in.v;

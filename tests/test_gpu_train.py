@@ -154,6 +154,19 @@ def test_timing_head_train_on_batch_vs_oracle(env):
     assert len(h.metrics_train) == 1
 
 
+@pytest.mark.parametrize('case', range(len(CASES)))
+def test_train_step_fast_forms_on_small_layers(env, case, monkeypatch):
+    """By default layers with fewer than 2048 output positions per batch stay on the GEMM path (a handful of workgroups
+    walking the whole contraction is slower there), so the small test graphs above never reach the trainer's forms of
+    the split-fp16 kernel for their kernel sizes / the masked small-image form.  AMT_TRAIN_FAST_MIN_M=0 sends every
+    covered layer through them: same oracle comparison, same bars."""
+    monkeypatch.setenv('AMT_TRAIN_FAST_MIN_M', '0')
+    net = env['rdcnn'].res_net(weight_seed=131 + case, calibrated=False, **CASES[case])
+    xs, y = _batch(net.cfg, 6, 500 + case)
+    w0 = {k: v.copy() for k, v in net.weights.items()}
+    _compare_step(env, net, xs, y, w0, None, 'fast-small case %d' % case)
+
+
 def test_training_paths_agree_at_full_width(env, monkeypatch):
     """The training step's fast forms against its plain ones on the metric shape (timing head, N = 2048: 20 x 516 input,
     batch of 3): split-fp16 forward convolutions / data gradients (conv_f16x3s_kernel, TRAIN form), the weight gradient
