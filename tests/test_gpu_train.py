@@ -103,6 +103,21 @@ def test_train_step_vs_oracle(env, case):
     assert np.abs(yp - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6)
 
 
+def test_train_batch_size_changes_between_steps(env, monkeypatch):
+    """The trainer (re)allocates its activation / gradient / reduction buffers when a larger batch arrives and keeps
+    weights, Adagrad accumulators and moving statistics across that: steps of 3, 7 and 2 windows on one net (fast forms
+    on, so the per-window maxima and the partial-sum buffers are resized too), each against the oracle from the
+    device's own state."""
+    monkeypatch.setenv('AMT_TRAIN_FAST_MIN_M', '0')
+    net = env['rdcnn'].res_net(weight_seed=77, calibrated=False, **CASES[1])
+    acc = None
+    for i, B in enumerate((3, 7, 2)):
+        xs, y = _batch(net.cfg, B, 900 + i)
+        net._sync_from_trainer() if i else None
+        w_dev = {k: v.copy() for k, v in net.weights.items()}
+        _, acc = _compare_step(env, net, xs, y, w_dev, acc, 'batch %d' % B)
+
+
 def test_velocity_head_first_step_and_learning(env):
     """The reference's smallest head (11 conv layers, 36 x 8 input) on a batch of 8 (main.py -batch_size): the first
     train_on_batch matches the oracle; and forty steps on a fixed batch drive the loss of two shallow nets (one
