@@ -28,20 +28,35 @@ struct amt_stft_plan {
 
 thread_local char amt_hip_err_buf[256] = {0};
 
+// (the magnitude-only 2048-point form fits 64 registers without spills: eight workgroups per CU, which is also what its
+// 20 KB of LDS allow)
+// Measured negative: the inter-stage twiddles are per-thread constants too (butterfly index = thread index), but
+// holding all of them costs 40 registers -> 138, three waves per SIMD: 1.43 ms against 1.20; capped at 128 / 96 registers
+// the compiler spills 8 / 37 of them.
 template <int N, bool WITH_PHASE>
-__global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
+__global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 8 : 1) void stft_mag_kernel(
     const float *__restrict__ wave, int L, size_t wave_stride,
     float *__restrict__ mag, float2 *__restrict__ phase, float *__restrict__ ref_max,
     int T, int ldf, size_t spec_stride, const float2 *__restrict__ tw_global,
     int hop, int center, int pairs_per_block) {
+    // the first pass of fft_block reads elements tid + r * (N / 8) (radix 8, one butterfly per thread for N = 2048):
+    // the same eight positions of every frame pair, so their Hann weights are formed once per workgroup, straight from
+    // the global table -- and the LDS copy then only needs the entries the inter-stage twiddles touch: k * N / (NS R)
+    // with k < NS, i.e. indices below N / 4 (the last pass is radix 4).  20 KB of LDS instead of 32: six workgroups per
+    // CU (the registers' limit) instead of five.
+    constexpr int NB1 = N / 8;
+    constexpr bool HOIST = NB1 == AMT_FFT_THREADS;
+    constexpr int TWN = HOIST ? N / 4 : N;
     __shared__ float2 buf[N];
-    __shared__ float2 tw[N];
-    // the reduction scratch aliases the FFT buffer (used once, after the last transform): at
-    // N = 2048 the kernel then needs exactly 32 KB of LDS and FIVE workgroups fit a CU, not four
+    __shared__ float2 tw[TWN];
+    // the reduction scratch aliases the FFT buffer (used once, after the last transform)
     float *red = reinterpret_cast<float *>(buf);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    for (int i = tid; i < N; i += AMT_FFT_THREADS) tw[i] = tw_global[i];
+    for (int i = tid; i < TWN; i += AMT_FFT_THREADS) tw[i] = tw_global[i];
+    float wn[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) wn[r] = HOIST ? 0.25f - 0.25f * tw_global[tid + r * NB1].x : 0.f;   // Hann / 2 (below)
     __syncthreads();
 
     const float *wv = wave + (size_t)b * wave_stride;
@@ -49,7 +64,6 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
     float2 *ph = WITH_PHASE ? phase + (size_t)b * spec_stride : nullptr;
     const int pad = center ? N / 2 : 0;
     float lmax = 0.f;
-
     for (int p = 0; p < pairs_per_block; ++p) {
         const int t0 = 2 * (blockIdx.x * pairs_per_block + p);
         if (t0 >= T) break;                       // uniform across the block
@@ -58,7 +72,7 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
         // interior pairs (both frames inside the signal) skip the reflect index map
         const bool interior = s0 >= 0 && (s0 + hop + N) <= L && has2;
         auto load_edge = [&](int n) -> float2 {
-            const float w = 0.5f - 0.5f * tw[n].x;
+            const float w = HOIST ? wn[(n - tid) / NB1] : 0.25f - 0.25f * tw[n].x;
             int i0 = s0 + n;
             int i1 = i0 + hop;
             // numpy 'reflect' (single reflection; pad = N/2 <= L-1 checked on host)
@@ -70,23 +84,53 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
         };
         const float *w0 = wv + s0;
         auto load_in = [&](int n) -> float2 {
-            const float w = 0.5f - 0.5f * tw[n].x;
+            const float w = HOIST ? wn[(n - tid) / NB1] : 0.25f - 0.25f * tw[n].x;
             return make_float2(w0[n] * w, w0[n + hop] * w);
         };
         if (interior) fft_block<N, false>(buf, tw, load_in);
         else fft_block<N, false>(buf, tw, load_edge);
 
+        // The window above is Hann / 2 (a power-of-two factor: exact), which is the 1/2 of the separation
+        //   X_t[k] = (Z[k] + conj Z[N-k]) / 2,  X_{t+1}[k] = (Z[k] - conj Z[N-k]) / (2i).
         float *m0 = mg + (size_t)t0 * ldf;
         float *m1 = m0 + ldf;
+        if constexpr (!WITH_PHASE) {
+            // magnitudes only: bins 0 .. N/2 - 1 in whole passes of the workgroup (no guard, v_sqrt_f32 instead of the
+            // rsq / compare / select / multiply the phase form needs), then bin N/2 and the pad columns by the first lanes
+            for (int k = tid; k < N / 2; k += AMT_FFT_THREADS) {
+                const float2 zk = buf[k];
+                const float2 zm = cconj(buf[(N - k) & (N - 1)]);
+                const float2 x0 = cadd(zk, zm);
+                const float2 d = csub(zk, zm);
+                const float a0 = __builtin_amdgcn_sqrtf(x0.x * x0.x + x0.y * x0.y);
+                const float a1 = __builtin_amdgcn_sqrtf(d.y * d.y + d.x * d.x);
+                lmax = fmaxf(lmax, a0);
+                m0[k] = a0;
+                if (has2) { lmax = fmaxf(lmax, a1); m1[k] = a1; }
+            }
+            for (int k = N / 2 + tid; k < ldf; k += AMT_FFT_THREADS) {     // ldf - N/2 = 4 columns: the first wave only
+                float a0 = 0.f, a1 = 0.f;
+                if (k == N / 2) {                                // Z[N/2] = X_t[N/2] + i X_{t+1}[N/2], both real
+                    const float2 zk = buf[N / 2];
+                    const float xr = zk.x + zk.x, xi = zk.y + zk.y;
+                    a0 = __builtin_amdgcn_sqrtf(xr * xr);
+                    a1 = __builtin_amdgcn_sqrtf(xi * xi);
+                    lmax = fmaxf(lmax, a0);
+                    if (has2) lmax = fmaxf(lmax, a1);
+                }
+                m0[k] = a0;
+                if (has2) m1[k] = a1;
+            }
+        } else {
         for (int k = tid; k < ldf; k += AMT_FFT_THREADS) {
             float a0 = 0.f, a1 = 0.f;
             float2 p0 = make_float2(0.f, 0.f), p1 = p0;
             if (k <= N / 2) {
                 const float2 zk = buf[k];
                 const float2 zm = cconj(buf[(N - k) & (N - 1)]);
-                const float2 x0 = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+                const float2 x0 = cadd(zk, zm);
                 const float2 d = csub(zk, zm);
-                const float2 x1 = make_float2(0.5f * d.y, -0.5f * d.x);
+                const float2 x1 = make_float2(d.y, -d.x);
                 // |X| = n2 * rsq(n2), X/|X| = X * rsq(n2)  (v_rsq_f32, ~1 ulp); 0 -> (0, 1+0i)
                 const float n0 = x0.x * x0.x + x0.y * x0.y;
                 const float n1 = x1.x * x1.x + x1.y * x1.y;
@@ -94,19 +138,16 @@ __global__ __launch_bounds__(AMT_FFT_THREADS) void stft_mag_kernel(
                 const float r1 = n1 > 1e-36f ? __builtin_amdgcn_rsqf(n1) : 0.f;
                 a0 = n0 * r0;
                 a1 = n1 * r1;
-                if (WITH_PHASE) {
-                    p0 = r0 > 0.f ? make_float2(x0.x * r0, x0.y * r0) : make_float2(1.f, 0.f);
-                    p1 = r1 > 0.f ? make_float2(x1.x * r1, x1.y * r1) : make_float2(1.f, 0.f);
-                }
+                p0 = r0 > 0.f ? make_float2(x0.x * r0, x0.y * r0) : make_float2(1.f, 0.f);
+                p1 = r1 > 0.f ? make_float2(x1.x * r1, x1.y * r1) : make_float2(1.f, 0.f);
                 lmax = fmaxf(lmax, a0);
                 if (has2) lmax = fmaxf(lmax, a1);
             }
             m0[k] = a0;
             if (has2) m1[k] = a1;
-            if (WITH_PHASE) {
-                ph[(size_t)t0 * ldf + k] = p0;
-                if (has2) ph[(size_t)(t0 + 1) * ldf + k] = p1;
-            }
+            ph[(size_t)t0 * ldf + k] = p0;
+            if (has2) ph[(size_t)(t0 + 1) * ldf + k] = p1;
+        }
         }
         // the next pair's first pass barriers before it overwrites `buf`
     }
@@ -348,7 +389,9 @@ static int launch_stft(const amt_stft_plan *plan, const float *wave, int B, int 
                        size_t wave_stride, float *mag, float *phase, float *ref_max, int T,
                        int ldf, size_t spec_stride, hipStream_t st) {
     const int pairs = (T + 1) / 2;
-    int ppb = 4;
+    static int ppb_max = 0;                              // AMT_STFT_PPB: frame pairs per workgroup (diagnostic)
+    if (!ppb_max) { const char *e = getenv("AMT_STFT_PPB"); ppb_max = (e && atoi(e) > 0) ? atoi(e) : 16; }
+    int ppb = ppb_max;
     // keep >= ~2048 workgroups in flight when the batch is small
     while (ppb > 1 && (size_t)((pairs + ppb - 1) / ppb) * B < 2048) ppb >>= 1;
     dim3 grid((pairs + ppb - 1) / ppb, B);
