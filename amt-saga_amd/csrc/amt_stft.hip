@@ -105,8 +105,10 @@ __global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 8 : 1
                 const float a0 = __builtin_amdgcn_sqrtf(x0.x * x0.x + x0.y * x0.y);
                 const float a1 = __builtin_amdgcn_sqrtf(d.y * d.y + d.x * d.x);
                 lmax = fmaxf(lmax, a0);
-                m0[k] = a0;
-                if (has2) { lmax = fmaxf(lmax, a1); m1[k] = a1; }
+                // streaming stores: the 2 GB of magnitudes are next read by other kernels, long after the L2 has turned
+                // over; kept out of it, the L2 holds the samples the NEXT frame pair re-reads (75 % overlap)
+                __builtin_nontemporal_store(a0, m0 + k);
+                if (has2) { lmax = fmaxf(lmax, a1); __builtin_nontemporal_store(a1, m1 + k); }
             }
             for (int k = N / 2 + tid; k < ldf; k += AMT_FFT_THREADS) {     // ldf - N/2 = 4 columns: the first wave only
                 float a0 = 0.f, a1 = 0.f;
@@ -392,8 +394,8 @@ static int launch_stft(const amt_stft_plan *plan, const float *wave, int B, int 
     static int ppb_max = 0;                              // AMT_STFT_PPB: frame pairs per workgroup (diagnostic)
     if (!ppb_max) { const char *e = getenv("AMT_STFT_PPB"); ppb_max = (e && atoi(e) > 0) ? atoi(e) : 16; }
     int ppb = ppb_max;
-    // keep >= ~2048 workgroups in flight when the batch is small
-    while (ppb > 1 && (size_t)((pairs + ppb - 1) / ppb) * B < 2048) ppb >>= 1;
+    // at least ~8 rounds of the 2048 workgroups the chip holds (8 per CU): fewer, longer workgroups leave a tail
+    while (ppb > 1 && (size_t)((pairs + ppb - 1) / ppb) * B < 16384) ppb >>= 1;
     dim3 grid((pairs + ppb - 1) / ppb, B);
     if (phase)
         stft_mag_kernel<N, true><<<grid, AMT_FFT_THREADS, 0, st>>>(
