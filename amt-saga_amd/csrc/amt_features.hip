@@ -10,8 +10,51 @@
 #include "amt_common.h"
 #include <algorithm>
 
-// One wave per (window, output frame): the row is read coalesced (lane + 64*q),
-// every band is a masked wave reduction.  F <= 64*MAXQ.
+// One wave per (window, output frame): the row is read coalesced (lane + 64*q) by 17 branch-free loads from clamped
+// addresses, all in flight together.
+//
+// Fast path -- the loop's own configuration, F = 1025 bins into the 20 log-spaced bands of util_audio.py:451-456
+// (edges 0 1 2 3 4 5 8 11 16 22 32 45 64 90 128 181 256 362 512 724 1025; checked against the caller's edge array by
+// scalar compares, uniform): with the edges known at compile time every band is a fixed list of whole and partial
+// registers -- no per-register skip branches (the generic form walks 17 uniform branches per band), masks only on the
+// partial ones -- and its wave reduction runs on the vector units alone: DPP row rotations inside the four 16-lane
+// rows, the four row totals by v_readlane.  One division and one store pass at the end (lane i holds band i).
+// Generic path (any edges / F): narrow bands lane-per-band through wave shuffles, wide bands by masked sums + a
+// shuffle reduction.  F <= 64*MAXQ.
+template <int N>
+__device__ __forceinline__ float cb_row_ror(float v) {                 // lane i of a 16-lane row <- lane (i + N) % 16
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float cb_wave_sum(float v) {
+    v += cb_row_ror<8>(v);
+    v += cb_row_ror<4>(v);
+    v += cb_row_ror<2>(v);
+    v += cb_row_ror<1>(v);                                             // every lane: the total of its 16-lane row
+    const int u = __float_as_int(v);                                   // (the builtin moves integers)
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(u, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(u, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(u, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(u, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+#define CB_STD_BANDS 20
+#define CB_STD_F 1025
+__device__ constexpr int cb_std_edge(int i) {
+    constexpr int e[CB_STD_BANDS + 1] = {0, 1, 2, 3, 4, 5, 8, 11, 16, 22, 32, 45, 64, 90, 128, 181, 256, 362, 512, 724, 1025};
+    return e[i];
+}
+template <int I, int MAXQ>
+__device__ __forceinline__ void cb_std_band(const float (&v)[MAXQ], int lane, float &mine) {
+    constexpr int lo = cb_std_edge(I), hi = cb_std_edge(I + 1);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        if (hi <= 64 * q || lo >= 64 * (q + 1)) continue;              // compile time: the band does not touch this register
+        if (lo <= 64 * q && hi >= 64 * (q + 1)) s += v[q];             // compile time: the whole register
+        else { const int f = lane + 64 * q; s += (f >= lo && f < hi) ? v[q] : 0.f; }
+    }
+    s = cb_wave_sum(s);
+    mine = lane == I ? s : mine;                            // a select: the reduction must run with every lane active
+    if constexpr (I + 1 < CB_STD_BANDS) cb_std_band<I + 1, MAXQ>(v, lane, mine);
+}
 template <int MAXQ>
 __global__ __launch_bounds__(256) void compress_bands_kernel(
     const float *__restrict__ mag, int T, int F, int ldf, size_t spec_stride,
@@ -23,16 +66,31 @@ __global__ __launch_bounds__(256) void compress_bands_kernel(
     if (j >= target) return;                                // whole wave exits together
     const int t = src_frame ? src_frame[j] : j;
     float v[MAXQ];
+    const bool frame_ok = t >= 0 && t < T;
+    const float *row = mag + (size_t)b * spec_stride + (size_t)(frame_ok ? t : 0) * ldf;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int f = lane + 64 * q;
-        v[q] = (t >= 0 && t < T && f < F) ? mag[(size_t)b * spec_stride + (size_t)t * ldf + f] : 0.f;
-    }
+    for (int q = 0; q < MAXQ; ++q) v[q] = row[min(lane + 64 * q, F - 1)];
     const float r = ref ? ref[b] : 1.0f;
     float *o = out + ((size_t)b * bands) * target + j;
-    // Bands that lie inside the first 64 bins (13 of the 20 log-spaced bands at F = 1025) are
-    // summed lane-per-band: lane i walks its band through wave shuffles of the first register --
-    // one pass of max-width steps for all of them instead of a 64-lane reduction each.  Wider
+    bool std_edges = MAXQ == 17 && bands == CB_STD_BANDS && F == CB_STD_F;
+    if (std_edges) {
+#pragma unroll
+        for (int i = 0; i <= CB_STD_BANDS; ++i) std_edges = std_edges && edges[i] == cb_std_edge(i);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) v[q] = (frame_ok && lane + 64 * q < F) ? v[q] : 0.f;
+    if constexpr (MAXQ == 17) {
+        if (std_edges) {                                    // uniform
+            float mine = 0.f;
+            cb_std_band<0, MAXQ>(v, lane, mine);
+            if (lane < CB_STD_BANDS)
+                o[(size_t)lane * target] = __fdiv_rn(__fdiv_rn(mine, (float)(edges[lane + 1] - edges[lane])), r);
+            return;
+        }
+    }
+    // ---- generic edges ------------------------------------------------------------------------------------------
+    // Bands that lie inside the first 64 bins are summed lane-per-band: lane i walks its band through wave shuffles of the
+    // first register -- one pass of max-width steps for all of them instead of a 64-lane reduction each.  Wider
     // bands: masked sums over the registers the band touches (uniform skips) + one wave reduction.
     const int my_lo = lane < bands ? edges[lane] : 0, my_hi = lane < bands ? edges[lane + 1] : 0;
     const bool narrow = lane < bands && my_hi <= 64;
