@@ -92,6 +92,7 @@ struct FcRowArgs {
     const float2 *tw;                            // [576] e^{-2 pi i m / 576}
     int B, H, W;
     int sf, sh;                                  // float strides of the frequency tensors: pair fp, image row h (window: 289 H 64)
+    unsigned long long *ts;                      // diagnostic (AMT_FC_TS): six 100-MHz timestamps per workgroup, or null
 };
 
 __device__ __forceinline__ float fc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
@@ -114,7 +115,9 @@ template <typename T> __device__ __forceinline__ T &fc_at(void *base, unsigned i
 // workgroups share a CU (4 + 4 + 2 + 2 waves fit four per SIMD at <= 128 registers; 2 x 78.8 KB of LDS) and run their
 // phases independently of each other instead of meeting at every barrier: 2.21 against 2.46 ms per chained layer of
 // 1024 windows on the same box.  ROWS = 2 (AMT_FC_ROWS=2) is the earlier 768-thread form described above.
-template <bool IN_FREQ, int ROWS = 2>
+// INREGS (IN_FREQ only): the epilogue on the transform's registers -- layers without a shortcut whose spatial output
+// nobody reads; its own instantiation, so that neither form carries the other's registers.
+template <bool IN_FREQ, int ROWS = 2, bool INREGS = false>
 __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_kernel(FcRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fc_smem[];
     const int half = (ROWS == 2 && threadIdx.x >= FC_THREADS) ? 1 : 0;
@@ -125,9 +128,14 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
     const int j24 = (tid & 3) + 4 * (tid >> 6);             // 0 .. 23
     const int row = min(ROWS * (int)blockIdx.x + half, a.B * a.H - 1);     // (an odd row count: the last row is done twice)
     const int b = row / a.H, h = row - b * a.H;
+    unsigned long long *tsp = a.ts ? a.ts + (size_t)blockIdx.x * 6 : nullptr;
+    if (tsp && threadIdx.x == 0) tsp[0] = wall_clock64();
     for (int i = threadIdx.x; i < FC_NF; i += ROWS * FC_THREADS) tw[i] = a.tw[i];
     float2 x[24];
     if (IN_FREQ) {
+        // (measured negative: touching the shortcut row's cache lines here by LDS-DMA loads, so that the epilogue's loads hit
+        // the L2, only moves the time from the epilogue into this phase: with shortcut and spatial output the row is bound
+        // by its 280 KB of traffic, not by the latency of one of its streams)
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
         const int k1 = j24;
         const float *yb = a.Yf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
+        if (tsp && threadIdx.x == 0) tsp[1] = wall_clock64();
 #pragma unroll
         for (int n2 = 0; n2 < 24; ++n2) {
             const float2 w = tw[n2 * k1];
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         for (int k = 0; k < 24; ++k) x[k] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (n2 * 24 + k) * 2);
         fc_fft24<true>(x);
         __syncthreads();                                    // every thread has read its column: `buf` becomes [w][pair]
+        if (tsp && threadIdx.x == 0) tsp[2] = wall_clock64();
         // ---- epilogue through LDS: the transform leaves 24 positions x 2 channels per thread in registers; adding 24
         // shortcut values to them there costs 48 more live registers and a second workgroup per CU (the kernel is bound
         // by memory latency: it needs two).  Instead the row goes to LDS position-major and a compact loop -- thread i:
@@ -159,6 +169,29 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         // (+ shortcut + BN) in place.
         float2 *ybuf = reinterpret_cast<float2 *>(buf);     // [576][16] complex = (channel 2 q, channel 2 q + 1)
         const float inv_n = 1.0f / (float)FC_NF;
+        // A layer without a shortcut whose spatial output nobody reads (every second layer of a chain) needs none of
+        // that: BN + sigmoid are per channel, the thread's pair is fixed, so they are applied to the registers the
+        // transform left and the forward transform starts from them -- no LDS round trip, three barriers fewer
+        // (8.2 of a row's 27.4 us went into this phase; same operations on the same values: bit-identical results).
+        if constexpr (INREGS) {
+            const int c0 = 2 * c16;
+            const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+            float vmax = 0.f;
+#pragma unroll
+            for (int n1 = 0; n1 < 24; ++n1) {
+                float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
+                v.x = fc_sigmoid(v.x * s1a + t1a);
+                v.y = fc_sigmoid(v.y * s1b + t1b);
+                if (24 * n1 + n2 >= a.W) v = make_float2(0.f, 0.f);
+                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+                x[n1] = v;
+            }
+            if (a.amax_out) {
+                vmax = wave_max(vmax);
+                if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
+            }
+            if (tsp && threadIdx.x == 0) tsp[3] = wall_clock64();
+        } else {
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) ybuf[(24 * n1 + n2) * 16 + c16] = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
         __syncthreads();
@@ -215,6 +248,7 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         }
         if (!a.Xf) return;
         __syncthreads();
+        if (tsp && threadIdx.x == 0) tsp[3] = wall_clock64();
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) {
             const int w = 24 * n1 + n2;
@@ -222,6 +256,7 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
             if (w >= a.W) x[n1] = make_float2(0.f, 0.f);
         }
         __syncthreads();                                    // `buf` is free for the forward transposition
+        }
     } else {
         // branch-free: the load goes to a clamped address and a select zeroes the padding (a conditional load is a branch,
         // and 24 branches are 24 serialised round trips to memory)
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
             *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (k1 * 24 + n2) * 2) = v;
         }
         __syncthreads();
+        if (tsp && threadIdx.x == 0) tsp[4] = wall_clock64();
         int k1 = j24, cp = c16;
         // (opaque copies: the 24 store offsets below depend only on thread constants, and hipcc otherwise computes them at
         // the top of the kernel and carries them -- through scratch memory -- across all four transforms)
@@ -267,6 +303,10 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         }
         fmax_ = wave_max(fmax_);
         if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amaxf) + b, __float_as_int(fmax_));
+        if (tsp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
+            if (threadIdx.x == 0) tsp[5] = wall_clock64();
+        }
     }
 }
 
@@ -556,19 +596,53 @@ static int fc_rows_per_wg() {
     return r;
 }
 template <bool IN_FREQ>
-static int fc_row_launch(const FcRowArgs &a, hipStream_t st) {
+static int fc_row_launch(const FcRowArgs &a_, hipStream_t st) {
+    FcRowArgs a = a_;
     const int rows = a.B * a.H;
+    // AMT_FC_TS=1 (diagnostic): phase split of a row workgroup's life
+    static const bool want_ts = getenv("AMT_FC_TS") != nullptr;
+    static unsigned long long *ts_dev = nullptr;
+    static size_t ts_cap = 0;
+    if (want_ts && IN_FREQ && a.Xf) {
+        if ((size_t)rows > ts_cap) {
+            if (ts_dev) (void)hipFree(ts_dev);
+            AMT_HIP_CHECK(hipMalloc(&ts_dev, (size_t)rows * 6 * sizeof(unsigned long long)));
+            ts_cap = rows;
+        }
+        a.ts = ts_dev;
+    }
     if (fc_rows_per_wg() == 1) {
         static bool attr1 = false;
         if (!attr1) {
             AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS1));
+            if (IN_FREQ)
+                AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, 1, IN_FREQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS1));
             attr1 = true;
         }
-        fc_row_kernel<IN_FREQ, 1><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
+        static const bool regs_ok = !(getenv("AMT_FC_INREGS") && atoi(getenv("AMT_FC_INREGS")) == 0);
+        if (IN_FREQ && regs_ok && !a.sc && !a.sc1 && !a.out_sp && a.Xf)
+            fc_row_kernel<IN_FREQ, 1, IN_FREQ><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
+        else
+            fc_row_kernel<IN_FREQ, 1><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
     } else {
         fc_row_kernel<IN_FREQ, 2><<<(rows + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
     }
     AMT_LAUNCH_CHECK();
+    if (a.ts && fc_rows_per_wg() == 1) {
+        AMT_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)rows * 6);
+        AMT_HIP_CHECK(hipMemcpy(h.data(), ts_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double d[5] = {0, 0, 0, 0, 0};
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < rows; ++i) {
+            for (int k = 0; k < 5; ++k) d[k] += (double)(h[6 * i + k + 1] - h[6 * i + k]);
+            t0 = std::min(t0, h[6 * i]); t1 = std::max(t1, h[6 * i + 5]);
+        }
+        fprintf(stderr, "fc_row_ts rows %d (sc %d sp %d): load+fft %.2f us, transpose+fft %.2f, ybuf+epilogue %.2f, regather+fft+transpose %.2f, "
+                        "fft+stores %.2f; kernel %.1f us = %.2f lives per slot of 512\n", rows, a.sc || a.sc1 ? 1 : 0, a.out_sp ? 1 : 0,
+                d[0] / rows / 100.0, d[1] / rows / 100.0, d[2] / rows / 100.0, d[3] / rows / 100.0, d[4] / rows / 100.0,
+                (double)(t1 - t0) / 100.0, (double)(t1 - t0) * 512.0 / (d[0] + d[1] + d[2] + d[3] + d[4]));
+    }
     return AMT_OK;
 }
 // persistent row kernels: `per_cu` workgroups per CU (what their registers / LDS allow)
