@@ -329,8 +329,12 @@ def main():
         fft_traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            fft_traffic = int((pj['fc_gemm']['hbm_bytes_per_launch'] / pj['fc_gemm']['windows_per_launch'] +
-                               pj['fc_row']['hbm_bytes_per_launch'] / pj['fc_row']['windows_per_launch']) * min(B, 1024))
+            per_w = lambda k: pj[k]['hbm_bytes_per_launch'] / pj[k]['windows_per_launch']
+            row = per_w('fc_row')
+            if 'fc_row_inregs' in pj:           # launches weighted: the layers with / without shortcut and spatial output
+                n0, n1 = pj['fc_row']['dispatches_in_class'], pj['fc_row_inregs']['dispatches_in_class']
+                row = (row * n0 + per_w('fc_row_inregs') * n1) / (n0 + n1)
+            fft_traffic = int((per_w('fc_gemm') + row) * min(B, 1024))
         except Exception:
             fft_traffic = None
         roofline_fft = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),

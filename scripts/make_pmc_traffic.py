@@ -23,7 +23,8 @@ FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false',
             'cqt_window_max': 'cqt_blocks_kernel<false', 'cqt_window_max_mfma': 'cqt_max_mfma_kernel',
             # conv mode 3: the FFT-domain layers (fc_row_kernel<true> = inverse + epilogue [+ forward]: its launches of a
             # chain differ in what they read and write -- shortcut, spatial output -- and are averaged)
-            'fc_gemm': 'fc_gemm_kernel', 'fc_row': 'fc_row_kernel<true', 'fc_row_first': 'fc_row_kernel<false'}
+            'fc_gemm': 'fc_gemm_kernel', 'fc_row': 'fc_row_kernel<true, 1, false', 'fc_row_inregs': 'fc_row_kernel<true, 1, true',
+            'fc_row_first': 'fc_row_kernel<false'}
 
 
 def load(path):
