@@ -61,8 +61,11 @@ PROTOTYPES = {
                             C.c_size_t, vp]),
     'amt_window_max': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp]),
     'amt_subtract': (C.c_int, [C.POINTER(SubtractArgs), vp]),
+    'amt_subtract_span': (C.c_int, [C.POINTER(SubtractArgs), vp, C.c_int, vp]),
     'amt_compress_bands': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp,
                                      C.c_int, vp, vp, vp, C.c_int, vp]),
+    'amt_compress_bands_fmax': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp,
+                                     C.c_int, vp, vp, vp, C.c_int, vp, vp]),
     'amt_short_window': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                    vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]),
     'amt_gather_frames': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, vp, C.c_int,

@@ -108,6 +108,7 @@ class AudioBatch:
         self.lib = _lib.load()
         self.wave = None
         self.mag = self.ph = self.ref_max = None
+        self._fmax = None            # (per-frame maxima [B, T], data_ptr of the mag they describe): compress_bands(fmax=True)
         self._max_scratch = None
         if wave is not None:
             w = to_dev(wave)
@@ -123,6 +124,7 @@ class AudioBatch:
     def stft(self, with_phase=True):
         """audio_complete.mag/.ph/.ref_mag for all windows (util_audio.py:139-174)."""
         B, T, ldf = self.B, self.T, self.ldf
+        self._fmax = None
         self.mag = empty((B, T, ldf))
         self.ph = empty((B, T, ldf, 2)) if with_phase else None
         self.ref_max = empty((B,))
@@ -149,11 +151,14 @@ class AudioBatch:
 
     # -- subtraction -----------------------------------------------------------------
     def subtract(self, guess_mag, guess_max=None, guess_index=None, guess_frames=None,
-                 offset_frames=None, normalize=True, relu=True, overkill_factor=1.0):
+                 offset_frames=None, normalize=True, relu=True, overkill_factor=1.0, span=False):
         """audio_complete.subtract for every window (util_audio.py:221-259).
         guess_mag [G, Tg, ldf] f32 frame-major; guess_index [B] int32 selects the
         guess per window; offset_frames [B] int32 is the already-clamped first frame
-        max(_seconds_to_frames(offset) - attack_compensation, 0)."""
+        max(_seconds_to_frames(offset) - attack_compensation, 0).
+        span=True (the caller vouches that mag is non-negative and unchanged since the compress_bands(fmax=True) that
+        left its per-frame maxima): amt_subtract_span touches only the frames the guess covers; same residual, same
+        maxima, ~2.5 x fewer bytes.  Falls back to the whole-window kernel when the maxima are not there."""
         B, T = self.mag.shape[0], self.mag.shape[1]
         a = _lib.SubtractArgs()
         new_max = empty((B,))
@@ -176,20 +181,33 @@ class AudioBatch:
         a.normalize = int(bool(normalize))
         a.relu = int(bool(relu))
         a.overkill_factor = float(overkill_factor)
-        _lib.check(self.lib.amt_subtract(C.byref(a), stream_ptr()))
+        fm = self._fmax
+        if span and relu and fm is not None and fm[1] == self.mag.data_ptr() and fm[0].shape == (B, T):
+            _lib.check(self.lib.amt_subtract_span(C.byref(a), ptr(fm[0]), int(guess_mag.shape[1]), stream_ptr()))
+        else:
+            self._fmax = None
+            _lib.check(self.lib.amt_subtract(C.byref(a), stream_ptr()))
         self.ref_max = new_max
         return self
 
     # -- features -------------------------------------------------------------------
-    def compress_bands(self, bands, ref=None, target_frames=None):
+    def compress_bands(self, bands, ref=None, target_frames=None, fmax=False):
         """_resize(compress_bands(mag, bands), target)/ref -> [B, bands, target]
-        (training.py:333-336)."""
+        (training.py:333-336).  fmax=True (identity frame map only): the kernel also leaves every frame's maximum, for
+        subtract(span=True)."""
         B, T = self.mag.shape[0], self.mag.shape[1]
         target = T if target_frames is None else int(target_frames)
         edges = _dev_table(('edges', self.F, bands), lambda: band_edges(self.F, bands))
         src = None if target == T else _dev_table(('resize', T, target),
                                                   lambda: resize_source_frames(T, target))
         out = empty((B, bands, target))
+        if fmax and src is None:
+            fm = empty((B, T))
+            _lib.check(self.lib.amt_compress_bands_fmax(
+                ptr(self.mag), B, T, self.F, self.ldf, T * self.ldf, ptr(edges), bands, ptr(ref),
+                None, ptr(out), target, ptr(fm), stream_ptr()))
+            self._fmax = (fm, self.mag.data_ptr())
+            return out
         _lib.check(self.lib.amt_compress_bands(
             ptr(self.mag), B, T, self.F, self.ldf, T * self.ldf, ptr(edges), bands, ptr(ref),
             ptr(src), ptr(out), target, stream_ptr()))

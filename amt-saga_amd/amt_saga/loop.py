@@ -69,6 +69,9 @@ class TranscriptionLoop:
             soundfont = _sf2.SoundFont(soundfont)
         self.soundfont = soundfont
         self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
+        # the subtraction on the guess's frames only (amt_subtract_span): the residual is a magnitude spectrogram (>= 0) and
+        # the timing features' compress_bands pass leaves the per-frame maxima on the way; AMT_SUBTRACT_SPAN=0: whole windows
+        self.span_subtract = os.environ.get('AMT_SUBTRACT_SPAN', '1') != '0'
         # diagnostic hook: when set to a list, iterate() appends one dict per iteration with copies of the heads'
         # pre-rounding outputs (what res_net.predict returns, RDCNN.py:591-597) -- the parity tests compare them
         # with the oracle's floats so that no window near a rounding tie leaves a test uncompared
@@ -206,7 +209,7 @@ class TranscriptionLoop:
         onset = end = pitch = program = velocity = None
         tr = {}
         if 'timing' in self.heads:
-            ct = b.compress_bands(p.timing_bands, self.refs['ref_mag'], p.timing_frames)
+            ct = b.compress_bands(p.timing_bands, self.refs['ref_mag'], p.timing_frames, fmax=self.span_subtract)
             if self.timing_streams == 2:
                 # the two timing networks read the same features and are independent: timing_end on a second stream
                 # fills the tails of timing_start's small-image launches (5 x 8 and 10 x 64 layers)
@@ -261,7 +264,8 @@ class TranscriptionLoop:
                 self.prog_group.shape[0], B, p.pitch_low, p.pitch_high - p.pitch_low + 1,
                 self.tail_frames, self.bank_frames, ptr(gidx), ptr(gfr), st))
             if self.guess == 'bank':
-                b.subtract(self.bank_mag, self.bank_max, gidx, gfr, onset, normalize=True, relu=True)
+                b.subtract(self.bank_mag, self.bank_max, gidx, gfr, onset, normalize=True, relu=True,
+                           span=self.span_subtract)
             else:
                 notes = empty((B, 1, 5))
                 _lib.check(self.lib.amt_guess_notes(
@@ -273,7 +277,7 @@ class TranscriptionLoop:
                 else:
                     gw = synth.render_windows_device(notes, self.bank_len, p.sr, timbres=self.timbres)
                 g = AudioBatch(gw, p.N, p.H).stft(with_phase=False)
-                b.subtract(g.mag, g.ref_max, None, gfr, onset, normalize=True, relu=True)
+                b.subtract(g.mag, g.ref_max, None, gfr, onset, normalize=True, relu=True, span=self.span_subtract)
         if self.trace is not None:
             self.trace.append({k: v.clone() for k, v in tr.items()})
         _lib.check(self.lib.amt_pack_events(B, int(window0), int(it), ptr(pitch), ptr(program),

@@ -59,7 +59,7 @@ template <int MAXQ>
 __global__ __launch_bounds__(256) void compress_bands_kernel(
     const float *__restrict__ mag, int T, int F, int ldf, size_t spec_stride,
     const int32_t *__restrict__ edges, int bands, const float *__restrict__ ref,
-    const int32_t *__restrict__ src_frame, float *__restrict__ out, int target) {
+    const int32_t *__restrict__ src_frame, float *__restrict__ out, int target, float *__restrict__ frame_max) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // output frame
     const int b = blockIdx.y;
@@ -79,6 +79,14 @@ __global__ __launch_bounds__(256) void compress_bands_kernel(
     }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) v[q] = (frame_ok && lane + 64 * q < F) ? v[q] : 0.f;
+    if (frame_max && frame_ok) {
+        // the frame is in registers anyway: its maximum, for amt_subtract_span (identity frame map: every frame once)
+        float m = v[0];
+#pragma unroll
+        for (int q = 1; q < MAXQ; ++q) m = fmaxf(m, v[q]);
+        m = wave_max(m);
+        if (lane == 0) frame_max[(size_t)b * T + t] = m;
+    }
     if constexpr (MAXQ == 17) {
         if (std_edges) {                                    // uniform
             float mine = 0.f;
@@ -241,24 +249,31 @@ __global__ __launch_bounds__(256) void spectral_flatness_kernel(
 
 extern "C" {
 
-int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
-                       const int32_t *edges, int bands, const float *ref,
-                       const int32_t *src_frame, float *out, int target_frames, void *stream) {
+int amt_compress_bands_fmax(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
+                            const int32_t *edges, int bands, const float *ref,
+                            const int32_t *src_frame, float *out, int target_frames, float *frame_max, void *stream) {
     if (!mag || !edges || !out || B <= 0 || T <= 0 || bands <= 0 || target_frames <= 0)
         return AMT_E_INVALID;
     if (F <= 0 || ldf < F) return AMT_E_SHAPE;
+    if (frame_max && (src_frame || target_frames != T)) return AMT_E_INVALID;       // every frame exactly once
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((target_frames + 3) / 4, B);
     if (F <= 64 * 5)
-        compress_bands_kernel<5><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+        compress_bands_kernel<5><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames, frame_max);
     else if (F <= 64 * 17)
-        compress_bands_kernel<17><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+        compress_bands_kernel<17><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames, frame_max);
     else if (F <= 64 * 33)
-        compress_bands_kernel<33><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames);
+        compress_bands_kernel<33><<<grid, 256, 0, st>>>(mag, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames, frame_max);
     else
         return AMT_E_UNSUPPORTED;
     AMT_LAUNCH_CHECK();
     return AMT_OK;
+}
+int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
+                       const int32_t *edges, int bands, const float *ref,
+                       const int32_t *src_frame, float *out, int target_frames, void *stream) {
+    return amt_compress_bands_fmax(mag, B, T, F, ldf, spec_stride, edges, bands, ref, src_frame, out, target_frames, nullptr,
+                                   stream);
 }
 
 int amt_short_window(const float *mag, const float *phase_ri, int B, int T, int F, int ldf,

@@ -270,7 +270,14 @@ def main():
             e0.record()
             r = fn(self, *a, **k)
             e1.record()
-            ev_pairs.append((tag, e0, e1, self.ph is not None if tag == 'stft' else None))
+            info = self.ph is not None if tag == 'stft' else None
+            if tag == 'subtract':
+                # what the launch touched: the whole windows, or (amt_subtract_span) the guess's frames of every window
+                gfr = a[3] if len(a) > 3 else k.get('guess_frames')
+                off = a[4] if len(a) > 4 else k.get('offset_frames')
+                info = dict(span=self._fmax is not None and bool(k.get('span', False)), gfr=gfr, off=off,
+                            guess_T=int(a[0].shape[1]), T=int(self.mag.shape[1]))
+            ev_pairs.append((tag, e0, e1, info))
             return r
         return w
     AudioBatch.stft, AudioBatch.subtract = timed(orig_stft, 'stft'), timed(orig_sub, 'subtract')
@@ -396,24 +403,42 @@ def main():
     n_sub = sum(1 for tag, _, _, _ in ev_pairs if tag == 'subtract')
     with_phase = any(ph for tag, _, _, ph in ev_pairs if tag == 'stft')
     stft_bytes = B * (4 * L + 4 * F * T + (8 * F * T if with_phase else 0))     # wave in, mag (+ unit phase) out
-    sub_bytes = B * (2 * 4 * F * T + 4 * F * loop.bank_frames) if n_sub else 0
+    # subtract: residual read + written, guess read -- over the whole window (amt_subtract) or over the frames the guess
+    # covers (amt_subtract_span: sum over the windows of min(offset + guess frames, T) - offset, from the launch's own tables)
+    sub_total, span_launches, span_frames = 0, 0, 0
+    for tag, _, _, info in ev_pairs:
+        if tag != 'subtract':
+            continue
+        if info['span'] and isinstance(info['gfr'], torch.Tensor) and isinstance(info['off'], torch.Tensor):
+            o = info['off'].clamp(min=0).long()
+            fr = (torch.minimum(o + info['gfr'].long(), torch.full_like(o, info['T'])) - o).clamp(min=0)
+            nfr = int(fr.sum().item())
+            sub_total += 3 * 4 * F * nfr + 2 * 4 * nfr + 4 * B * info['T']
+            span_launches += 1
+            span_frames += nfr
+        else:
+            sub_total += B * (2 * 4 * F * T + 4 * F * loop.bank_frames)
+    sub_bytes = sub_total / n_sub if n_sub else 0
     hbm_ms = stft_ms + sub_ms
     hbm_gbs = (n_stft * stft_bytes + n_sub * sub_bytes) / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else 0.0
     stft_traffic = None
     try:
         key = 'stft' if with_phase else 'stft_mag_only'
         stft_traffic = int(pmc[key]['hbm_bytes_per_launch'] * B / pmc[key]['windows_per_launch'] +
-                           (pmc['subtract']['hbm_bytes_per_launch'] * B / pmc['subtract']['windows_per_launch']
-                            if n_sub else 0))
+                           (pmc['subtract_span' if span_launches else 'subtract']['hbm_bytes_per_launch'] * B /
+                            pmc['subtract_span' if span_launches else 'subtract']['windows_per_launch'] if n_sub else 0))
     except Exception:
         stft_traffic = None
     roofline_stft = dict(bound='hbm', achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                          frac=round(hbm_gbs / HBM_PEAK_GBS, 4), traffic=stft_traffic,
                          algorithmic_bytes=int(stft_bytes + sub_bytes),
-                         kernel='stft_mag_kernel<2048,%s> + subtract_kernel' % ('phase' if with_phase else 'mag only'),
+                         kernel='stft_mag_kernel<2048,%s> + %s' % ('phase' if with_phase else 'mag only',
+                                                                   'subtract_span_kernel' if span_launches else 'subtract_kernel'),
                          phase_plane_stored=bool(with_phase),
                          stft_gbs=round(n_stft * stft_bytes / (stft_ms * 1e-3) / 1e9, 1) if stft_ms else None,
                          subtract_gbs=round(n_sub * sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
+                         subtract_form=('span: %.1f of %d frames per window' % (span_frames / max(span_launches, 1) / B, T)
+                                        if span_launches else 'whole window'),
                          ms_per_step=round(hbm_ms / args.steps, 3))
 
     # ---- extra legs, same run ----------------------------------------------------------------

@@ -104,6 +104,14 @@ typedef struct amt_subtract_args {
 
 int amt_subtract(const amt_subtract_args *args, void *stream);
 
+/* The same step on the frames that change (util_audio.py:250-259 writes only self.mag[:, off:off + Tg]): reads and
+ * writes frames [offset, offset + guess_frames) of every window, updates their entries of frame_max [B][T] and sets
+ * new_max[b] = max over t of frame_max[b][t].  Preconditions, the caller's: relu != 0; resid >= 0 everywhere (magnitudes,
+ * or the output of an earlier step), so that the ReLU leaves the other frames as they are; frame_max[b][t] = the maximum
+ * of resid's frame t over the F bins (amt_compress_bands_fmax leaves it).  span_cap >= every window's guess frame count
+ * (the guess tensor's frames).  Residual and maxima are bit-identical to amt_subtract's. */
+int amt_subtract_span(const amt_subtract_args *args, float *frame_max, int span_cap, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * Feature gathers (audio_complete.compress_bands :436-466, ._resize :384-409,
  * .resize :469-507, .section_power :334-349 and the recipe of
@@ -119,6 +127,12 @@ int amt_compress_bands(const float *mag, int B, int T, int F, int ldf, size_t sp
                        const int32_t *edges, int bands, const float *ref,
                        const int32_t *src_frame, float *out, int target_frames,
                        void *stream);
+/* The same, also leaving frame_max [B][T] = max over the F bins of every frame (the kernel has the frame in registers):
+ * what amt_subtract_span needs.  Identity frame map only (src_frame NULL, target_frames == T). */
+int amt_compress_bands_fmax(const float *mag, int B, int T, int F, int ldf, size_t spec_stride,
+                            const int32_t *edges, int bands, const float *ref,
+                            const int32_t *src_frame, float *out, int target_frames,
+                            float *frame_max, void *stream);
 
 /* short-window gather: for every window b take frames src_frame[b][0..frames)
  * (-1 => zeros; the table realises _resize's tile/crop rule) and rows

@@ -19,7 +19,7 @@ tag = sys.argv[4] if len(sys.argv) > 4 else ''
 FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false',
             'conv_mfma': 'conv_mfma_kernel<4, 16, 32, 32',
             'stft': 'stft_mag_kernel<2048, true', 'stft_mag_only': 'stft_mag_kernel<2048, false',
-            'subtract': 'subtract_kernel', 'compress_bands': 'compress_bands_kernel',
+            'subtract': 'subtract_kernel', 'subtract_span': 'subtract_span_kernel', 'compress_bands': 'compress_bands_kernel',
             'cqt_window_max': 'cqt_blocks_kernel<false', 'cqt_window_max_mfma': 'cqt_max_mfma_kernel',
             # conv mode 3: the FFT-domain layers (fc_row_kernel<true> = inverse + epilogue [+ forward]: its launches of a
             # chain differ in what they read and write -- shortcut, spatial output -- and are averaged)

@@ -409,3 +409,50 @@ def test_db_and_flatness_on_device(mods):
     fo = oa.AudioCompleteOracle(noise, 2048).spectral_flatness()
     assert abs(fn - fo) < 1e-4 and fn > 0.3 > f_tone
 
+
+def test_subtract_span_equals_whole_window(mods):
+    """amt_subtract_span (only the frames the guess covers, per-frame maxima from amt_compress_bands_fmax) against
+    amt_subtract on the same non-negative spectrograms: residual and new maxima bit for bit, the per-frame maxima equal
+    to the rows' maxima afterwards; guesses of per-window lengths incl. 0, offsets at 0 / inside / running over the end;
+    a second step from the updated maxima; and the fallbacks (no maxima, relu off)."""
+    audio, _ = mods
+    import torch
+    rng = np.random.default_rng(11)
+    B, T, n_fft = 5, 40, 2048
+    wave = np.stack([_signal(512 * (T - 1), 70 + s) for s in range(B)])
+    gw = np.stack([_signal(512 * 12, 90 + s) * (0.5 + s) for s in range(3)])
+    g = audio.AudioBatch(gw, n_fft).stft(False)
+    gidx = torch.tensor([0, 2, 1, 1, 0], dtype=torch.int32).cuda()
+    gfr = torch.tensor([13, 0, 7, 13, 5], dtype=torch.int32).cuda()
+    for offs in ([0, 3, 35, 39, 12], [1, 0, 0, 30, 37]):
+        off = torch.tensor(offs, dtype=torch.int32).cuda()
+        a = audio.AudioBatch(wave, n_fft).stft(False)
+        b = audio.AudioBatch(wave, n_fft).stft(False)
+        ref = a.ref_max.clone()
+        a.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True)
+        b.compress_bands(20, ref, T, fmax=True)
+        fm = b._fmax[0]
+        assert torch.equal(fm, b.mag[:, :, :1025].amax(dim=2))
+        b.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True, span=True)
+        assert b._fmax is not None                                   # the span kernel ran and kept the maxima
+        assert torch.equal(a.mag, b.mag) and torch.equal(a.ref_max, b.ref_max)
+        assert torch.equal(b._fmax[0], b.mag[:, :, :1025].amax(dim=2))
+        # a second step straight from the updated maxima
+        a.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True)
+        b.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True, span=True)
+        assert torch.equal(a.mag, b.mag) and torch.equal(a.ref_max, b.ref_max)
+    # without maxima, or without the ReLU, span=True is the whole-window kernel
+    c = audio.AudioBatch(wave, n_fft).stft(False)
+    c.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True, span=True)
+    d = audio.AudioBatch(wave, n_fft).stft(False)
+    d.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=True)
+    assert torch.equal(c.mag, d.mag) and c._fmax is None
+    e = audio.AudioBatch(wave, n_fft).stft(False)
+    e.compress_bands(20, None, T, fmax=True)
+    e.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=False, span=True)
+    f = audio.AudioBatch(wave, n_fft).stft(False)
+    f.subtract(g.mag, g.ref_max, gidx, gfr, off, normalize=True, relu=False)
+    assert torch.equal(e.mag, f.mag) and torch.equal(e.ref_max, f.ref_max) and e._fmax is None
+    from amt_saga import _lib
+    assert _lib.load().amt_compress_bands_fmax(c.mag.data_ptr(), B, T, 1025, c.ldf, T * c.ldf, gidx.data_ptr(), 20, None,
+                                               gidx.data_ptr(), c.mag.data_ptr(), T, c.mag.data_ptr(), None) == _lib.AMT_E_INVALID
