@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgArgs a) {
         const float *xa = xs + (half + wid * TPW) * 32 + n;
         const float *db = ds + half * 32 + n;
         const int ksteps = (len + 1) >> 1;
-#pragma unroll 4
         for (int q = 0; q < ksteps; ++q) {
             const float bv = db[q * 64];
 #pragma unroll
@@ -758,7 +757,7 @@ struct amt_trainer {
     int flat = 0, capB = 0;
     float lr = 0.01f, eps = 1e-7f, acc0 = 0.f;
     float *col = nullptr, *part = nullptr, *red0 = nullptr, *red1 = nullptr, *stat0 = nullptr, *stat1 = nullptr;
-    float *pred = nullptr, *loss_rows = nullptr, *dlogits = nullptr, *y_dev = nullptr;
+    float *pred = nullptr, *loss_rows = nullptr, *dlogits = nullptr;
     size_t col_cap = 0, part_cap = 0;
     std::vector<float *> allocs;
     // split-fp16 convolutions: per-layer weight jobs (device copy), max |w| / exponent slots, per-window operand maxima
@@ -1128,7 +1127,7 @@ static int ensure_batch(amt_trainer *t, int B) {
     }
     const int K = t->d.output_classes;
     if (talloc(t, (size_t)B * K, &t->pred) != AMT_OK || talloc(t, B, &t->loss_rows) != AMT_OK ||
-        talloc(t, (size_t)B * K, &t->dlogits) != AMT_OK || talloc(t, B, &t->y_dev) != AMT_OK)
+        talloc(t, (size_t)B * K, &t->dlogits) != AMT_OK)
         return AMT_E_NOMEM;
     t->capB = B;
     return AMT_OK;
