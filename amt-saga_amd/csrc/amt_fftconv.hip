@@ -30,10 +30,11 @@
 
 #define FC_NF 576
 #define FC_NP 289
-#define FC_PS 1160                      // dwords per channel pair in the LDS transposition buffer (576 complex + 8 pad)
+#define FC_PS 1158                      // dwords per channel pair in the LDS transposition buffer (576 complex + 6 pad: the 64-bit
+                                        // reads, 16 pairs x four columns 48 dwords apart per wave, then touch every bank pair once; 1160
+                                        // made them four-way conflicts; the writes are two-way now, inside their issue time)
 #define FC_THREADS 384                  // 16 channel pairs x 24
 #define FC_LSCALE 2048.0f
-#define FC_DEFAULT_LAYOUT 0
 
 typedef _Float16 fc_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fc_h4 __attribute__((ext_vector_type(4)));
@@ -80,9 +81,9 @@ __device__ __forceinline__ void fc_fft24(float2 (&x)[24]) {
 
 struct FcRowArgs {
     const float *in_sp; size_t in_stride;        // [B][H][W][32] spatial input (first layer of a chain), or null
-    const float *Yf;                             // [289][B][H][64] products of the GEMM (all other layers), or null
+    const float *Yf;                             // [B][289][H][64] products of the GEMM (all other layers), or null
     float *out_sp; size_t out_stride;            // spatial output [B][H][W][32], or null (no later reader)
-    float *Xf;                                   // [289][B][H][64] transform of the output for the next layer, or null
+    float *Xf;                                   // [B][289][H][64] transform of the output for the next layer, or null
     float *amaxf;                                // [B] max |Xf| per window (atomicMax, zeroed by the caller), with Xf
     float *amax_out;                             // [B] max |spatial output| per window, or null
     const float *s1, *t1, *s2, *t2;              // folded BN (+ conv bias); s2 / t2 null without a residual
@@ -92,10 +93,16 @@ struct FcRowArgs {
     const float2 *tw;                            // [576] e^{-2 pi i m / 576}
     int B, H, W;
     int sf, sh;                                  // float strides of the frequency tensors: pair fp, image row h (window: 289 H 64)
-    unsigned long long *ts;                      // diagnostic (AMT_FC_TS): six 100-MHz timestamps per workgroup, or null
 };
 
-__device__ __forceinline__ float fc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// 1 / (1 + e^-v): v_rcp_f32 + one Newton step instead of the IEEE division sequence (ten instructions, 48 times per
+// thread and row: a sixth of the row kernel's vector instructions).  The step leaves the quotient within an ulp of the
+// correctly rounded one; the argument is clamped so that 1 + e^-v stays finite (the step would turn 0 x inf into NaN).
+__device__ __forceinline__ float fc_sigmoid(float v) {
+    const float d = 1.0f + __expf(-fmaxf(v, -87.0f));
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
 // uniform base + unsigned 32-bit byte offset: the access takes its base from scalar registers and ONE address VGPR (as
 // 64-bit per-lane pointers the 72 addresses of a row thread alone overflowed the register file)
 template <typename T> __device__ __forceinline__ const T &fc_at(const void *base, unsigned int off) {
@@ -105,37 +112,29 @@ template <typename T> __device__ __forceinline__ T &fc_at(void *base, unsigned i
     return *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(base) + off);
 }
 
-// One workgroup per image row (b, h).  IN_FREQ: inverse transform of Yf + epilogue; else the spatial input is loaded.
-// Then (a.Xf) the forward transform.
-// Two image rows per 768-thread workgroup, each half (384 threads, six waves) with its own transposition buffer: the
-// kernel is bound by memory latency and needs two rows in flight per CU, but two SEPARATE 6-wave workgroups of 168
-// registers do not fit a CU's SIMDs together (2 + 2 waves on one SIMD > 3) -- measured: one resident, 66 % of the wave
-// cycles waiting -- while twelve waves of ONE workgroup spread three per SIMD.
-// ROWS = 1 (default since the registers fit: 128, no spills): one row per 384-thread workgroup, so that TWO such
-// workgroups share a CU (4 + 4 + 2 + 2 waves fit four per SIMD at <= 128 registers; 2 x 78.8 KB of LDS) and run their
-// phases independently of each other instead of meeting at every barrier: 2.21 against 2.46 ms per chained layer of
-// 1024 windows on the same box.  ROWS = 2 (AMT_FC_ROWS=2) is the earlier 768-thread form described above.
-// INREGS (IN_FREQ only): the epilogue on the transform's registers -- layers without a shortcut whose spatial output
-// nobody reads; its own instantiation, so that neither form carries the other's registers.
-template <bool IN_FREQ, int ROWS = 2, bool INREGS = false>
-__global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_kernel(FcRowArgs a) {
+// One 384-thread workgroup per image row (b, h); TWO such workgroups share a CU (<= 128 registers: 4 + 4 + 2 + 2 waves fit
+// four per SIMD; 2 x 78.7 KB of LDS) and run their phases independently of each other.  IN_FREQ: inverse transform of Yf +
+// epilogue; else the spatial input is loaded.  Then (a.Xf) the forward transform.
+// The epilogue runs on the registers the inverse transform leaves (24 positions x one channel pair per thread: BN + sigmoid
+// are per channel, the thread's pair is fixed) and the forward transform starts from them.  EPI = 1: no shortcut, no spatial
+// output (every second layer of a chain).  EPI = 2: shortcut (identity tensor or the rank-1 projection of the one-channel
+// input), spatial output and its per-window maximum as the arguments ask: the 24 shortcut values of a thread are requested
+// in one burst after the transform (a wave's instruction covers four positions x 128 bytes = 512 contiguous bytes) and the
+// outputs leave from the registers the same way.  (Round 3 sent that form through an LDS round trip -- position-major
+// copy, compact loop, re-gather, three barriers: 16.5 us of a row's 37.)
+template <bool IN_FREQ, int EPI>
+__global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fc_smem[];
-    const int half = (ROWS == 2 && threadIdx.x >= FC_THREADS) ? 1 : 0;
-    const int tid = threadIdx.x - half * FC_THREADS;
-    float *buf = fc_smem + (size_t)half * 16 * FC_PS;       // [16][FC_PS] per half
-    float2 *tw = reinterpret_cast<float2 *>(fc_smem + ROWS * 16 * FC_PS);
+    const int tid = threadIdx.x;
+    float *buf = fc_smem;                                   // [16][FC_PS]
+    float2 *tw = reinterpret_cast<float2 *>(fc_smem + 16 * FC_PS);
     const int c16 = (tid >> 2) & 15;                        // channel pair
     const int j24 = (tid & 3) + 4 * (tid >> 6);             // 0 .. 23
-    const int row = min(ROWS * (int)blockIdx.x + half, a.B * a.H - 1);     // (an odd row count: the last row is done twice)
+    const int row = blockIdx.x;
     const int b = row / a.H, h = row - b * a.H;
-    unsigned long long *tsp = a.ts ? a.ts + (size_t)blockIdx.x * 6 : nullptr;
-    if (tsp && threadIdx.x == 0) tsp[0] = wall_clock64();
-    for (int i = threadIdx.x; i < FC_NF; i += ROWS * FC_THREADS) tw[i] = a.tw[i];
+    for (int i = tid; i < FC_NF; i += FC_THREADS) tw[i] = a.tw[i];
     float2 x[24];
     if (IN_FREQ) {
-        // (measured negative: touching the shortcut row's cache lines here by LDS-DMA loads, so that the epilogue's loads hit
-        // the L2, only moves the time from the epilogue into this phase: with shortcut and spatial output the row is bound
-        // by its 280 KB of traffic, not by the latency of one of its streams)
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
         const int k1 = j24;
         const float *yb = a.Yf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
@@ -147,7 +146,6 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
-        if (tsp && threadIdx.x == 0) tsp[1] = wall_clock64();
 #pragma unroll
         for (int n2 = 0; n2 < 24; ++n2) {
             const float2 w = tw[n2 * k1];
@@ -160,103 +158,87 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
 #pragma unroll
         for (int k = 0; k < 24; ++k) x[k] = *reinterpret_cast<const float2 *>(buf + c16 * FC_PS + (n2 * 24 + k) * 2);
         fc_fft24<true>(x);
-        __syncthreads();                                    // every thread has read its column: `buf` becomes [w][pair]
-        if (tsp && threadIdx.x == 0) tsp[2] = wall_clock64();
-        // ---- epilogue through LDS: the transform leaves 24 positions x 2 channels per thread in registers; adding 24
-        // shortcut values to them there costs 48 more live registers and a second workgroup per CU (the kernel is bound
-        // by memory latency: it needs two).  Instead the row goes to LDS position-major and a compact loop -- thread i:
-        // position i / 16, pair i % 16, 64-bit coalesced shortcut loads and output stores -- applies BN + sigmoid
-        // (+ shortcut + BN) in place.
-        float2 *ybuf = reinterpret_cast<float2 *>(buf);     // [576][16] complex = (channel 2 q, channel 2 q + 1)
+        // ---- epilogue on the registers
         const float inv_n = 1.0f / (float)FC_NF;
-        // A layer without a shortcut whose spatial output nobody reads (every second layer of a chain) needs none of
-        // that: BN + sigmoid are per channel, the thread's pair is fixed, so they are applied to the registers the
-        // transform left and the forward transform starts from them -- no LDS round trip, three barriers fewer
-        // (8.2 of a row's 27.4 us went into this phase; same operations on the same values: bit-identical results).
-        if constexpr (INREGS) {
-            const int c0 = 2 * c16;
-            const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
-            float vmax = 0.f;
+        const int c0 = 2 * c16;
+        const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+        if constexpr (EPI == 1) {
 #pragma unroll
             for (int n1 = 0; n1 < 24; ++n1) {
                 float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
                 v.x = fc_sigmoid(v.x * s1a + t1a);
                 v.y = fc_sigmoid(v.y * s1b + t1b);
                 if (24 * n1 + n2 >= a.W) v = make_float2(0.f, 0.f);
-                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
                 x[n1] = v;
             }
-            if (a.amax_out) {
-                vmax = wave_max(vmax);
-                if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
-            }
-            if (tsp && threadIdx.x == 0) tsp[3] = wall_clock64();
         } else {
-#pragma unroll
-        for (int n1 = 0; n1 < 24; ++n1) ybuf[(24 * n1 + n2) * 16 + c16] = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
-        __syncthreads();
-        {
-            const int q = tid & 15, c0 = 2 * q;
-            const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
-            const bool res = a.s2 != nullptr;
-            const float s2a = res ? a.s2[c0] : 1.f, s2b = res ? a.s2[c0 + 1] : 1.f;
-            const float t2a = res ? a.t2[c0] : 0.f, t2b = res ? a.t2[c0 + 1] : 0.f;
+            // EPI = 2: identity shortcut tensor; 3: rank-1 shortcut (the projected one-channel input); 4: none.  All write
+            // the spatial output.
+            constexpr bool RES = EPI == 2 || EPI == 3;
+            const float s2a = RES ? a.s2[c0] : 1.f, s2b = RES ? a.s2[c0 + 1] : 1.f;
+            const float t2a = RES ? a.t2[c0] : 0.f, t2b = RES ? a.t2[c0 + 1] : 0.f;
+            const float *scb = EPI == 2 ? a.sc + (size_t)b * a.sc_stride + (size_t)h * a.W * 32 : nullptr;
+            const float *sc1b = EPI == 3 ? a.sc1 + (size_t)b * a.sc1_stride + (size_t)h * a.W : nullptr;
+            float *ob = a.out_sp + (size_t)b * a.out_stride + (size_t)h * a.W * 32;
+            // (opaque copy: the access offsets below depend only on thread constants, and hipcc otherwise forms all of
+            // them at the top of the kernel and carries them -- through scratch memory -- across the transforms)
+            int n2e = n2;
+            asm volatile("" : "+v"(n2e));
+            const unsigned int voff = (unsigned)((n2e * 32 + c0) * 4), wlim = (unsigned)((a.W - 1) * 128 + c0 * 4);
             float pw0 = 0.f, pw1 = 0.f, ps0 = 0.f, ps1 = 0.f, pt0 = 0.f, pt1 = 0.f;
-            if (a.sc1) {
+            if constexpr (EPI == 3) {
                 pw0 = a.sc1_w[c0]; pw1 = a.sc1_w[c0 + 1]; ps0 = a.sc1_s[c0]; ps1 = a.sc1_s[c0 + 1];
                 pt0 = a.sc1_t[c0]; pt1 = a.sc1_t[c0 + 1];
             }
-            const float *scb = a.sc ? a.sc + (size_t)b * a.sc_stride + (size_t)h * a.W * 32 : nullptr;
-            const float *sc1b = a.sc1 ? a.sc1 + (size_t)b * a.sc1_stride + (size_t)h * a.W : nullptr;
-            float *ob = a.out_sp ? a.out_sp + (size_t)b * a.out_stride + (size_t)h * a.W * 32 : nullptr;
-            float vmax = 0.f;
-            const int n_el = a.W * 16;                      // (FC_THREADS is a multiple of 16: a thread keeps its pair)
-            constexpr int NIT = FC_NF * 16 / FC_THREADS;    // 24 elements per thread at most
-            // every shortcut value of the thread is requested before the first is used (clamped address, no branch): the
-            // row's registers are in LDS at this point, so the 24 values fit
-            float2 scv[NIT];
-            if (scb) {
+            // the thread's 24 shortcut values arrive in batches of NB, one batch ahead of the one being used (clamped
+            // addresses, no branch): all 24 at once are 48 registers beside the 48 of the row and spill
+            constexpr int NB = 4;
+            float2 scv[2][NB];
+            auto request = [&](int batch, float2 (&dst)[NB]) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) scv[it] = fc_at<float2>(scb, (unsigned)(min(tid + FC_THREADS * it, n_el - 1) * 8));
-            } else if (sc1b) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) scv[it].x = fc_at<float>(sc1b, (unsigned)((min(tid + FC_THREADS * it, n_el - 1) >> 4) * 4));
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = tid + FC_THREADS * it;
-                if (i >= n_el) break;
-                float2 v = ybuf[i];
-                v.x = fc_sigmoid(v.x * s1a + t1a);
-                v.y = fc_sigmoid(v.y * s1b + t1b);
-                if (scb) {
-                    v.x = (v.x + scv[it].x) * s2a + t2a;
-                    v.y = (v.y + scv[it].y) * s2b + t2b;
-                } else if (sc1b) {
-                    const float xi = scv[it].x;
-                    v.x = (v.x + (fmaf(xi, pw0, 0.f) * ps0 + pt0)) * s2a + t2a;
-                    v.y = (v.y + (fmaf(xi, pw1, 0.f) * ps1 + pt1)) * s2b + t2b;
+                for (int i = 0; i < NB; ++i) {
+                    const unsigned int o = min(voff + (unsigned)(24 * (batch * NB + i) * 128), wlim);
+                    if constexpr (EPI == 2) dst[i] = fc_at<float2>(scb, o);
+                    if constexpr (EPI == 3) dst[i].x = fc_at<float>(sc1b, (o >> 7) * 4);
                 }
-                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-                if (ob) fc_at<float2>(ob, (unsigned)(i * 8)) = v;
-                ybuf[i] = v;
+            };
+            float vmax = 0.f;
+            if constexpr (RES) request(0, scv[0]);
+#pragma unroll
+            for (int batch = 0; batch < 24 / NB; ++batch) {
+                if constexpr (RES) {
+                    if (batch + 1 < 24 / NB) request(batch + 1, scv[(batch + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int n1 = batch * NB + i, w = 24 * n1 + n2e;
+                    float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
+                    v.x = fc_sigmoid(v.x * s1a + t1a);
+                    v.y = fc_sigmoid(v.y * s1b + t1b);
+                    if constexpr (EPI == 2) {
+                        v.x = (v.x + scv[batch & 1][i].x) * s2a + t2a;
+                        v.y = (v.y + scv[batch & 1][i].y) * s2b + t2b;
+                    }
+                    if constexpr (EPI == 3) {
+                        const float xi = scv[batch & 1][i].x;
+                        v.x = (v.x + (fmaf(xi, pw0, 0.f) * ps0 + pt0)) * s2a + t2a;
+                        v.y = (v.y + (fmaf(xi, pw1, 0.f) * ps1 + pt1)) * s2b + t2b;
+                    }
+                    if (w >= a.W) v = make_float2(0.f, 0.f);
+                    vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+                    if (w < a.W) fc_at<float2>(ob, voff + (unsigned)(24 * n1 * 128)) = v;
+                    x[n1] = v;
+                }
+                if constexpr (RES) __builtin_amdgcn_sched_barrier(0);
             }
             if (a.amax_out) {
                 vmax = wave_max(vmax);
                 if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amax_out) + b, __float_as_int(vmax));
             }
+            if (!a.Xf) return;
         }
-        if (!a.Xf) return;
-        __syncthreads();
-        if (tsp && threadIdx.x == 0) tsp[3] = wall_clock64();
-#pragma unroll
-        for (int n1 = 0; n1 < 24; ++n1) {
-            const int w = 24 * n1 + n2;
-            x[n1] = ybuf[min(w, a.W - 1) * 16 + c16];
-            if (w >= a.W) x[n1] = make_float2(0.f, 0.f);
-        }
-        __syncthreads();                                    // `buf` is free for the forward transposition
-        }
+        __syncthreads();                                    // every thread has read its column: `buf` is free for the forward transposition
     } else {
         // branch-free: the load goes to a clamped address and a select zeroes the padding (a conditional load is a branch,
         // and 24 branches are 24 serialised round trips to memory)
@@ -274,15 +256,17 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
     }
     // ---- forward: thread (p = c16, n2 = j24) transforms over n1 -> k1, twiddles, transposition, (p, k1 = j24) over n2 -> k2
     {
-        const int n2 = j24;
+        // (opaque copies here too: the twiddle and LDS addresses of this phase are the inverse transposition's, and hipcc
+        // otherwise keeps all of them alive from there -- through scratch memory -- across the epilogue)
+        int n2 = j24, cq = c16;
+        asm volatile("" : "+v"(n2), "+v"(cq));
         fc_fft24<false>(x);
 #pragma unroll
         for (int k1 = 0; k1 < 24; ++k1) {
             const float2 v = cmul(x[k1], tw[n2 * k1]);
-            *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (k1 * 24 + n2) * 2) = v;
+            *reinterpret_cast<float2 *>(buf + cq * FC_PS + (k1 * 24 + n2) * 2) = v;
         }
         __syncthreads();
-        if (tsp && threadIdx.x == 0) tsp[4] = wall_clock64();
         int k1 = j24, cp = c16;
         // (opaque copies: the 24 store offsets below depend only on thread constants, and hipcc otherwise computes them at
         // the top of the kernel and carries them -- through scratch memory -- across all four transforms)
@@ -303,10 +287,6 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
         }
         fmax_ = wave_max(fmax_);
         if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amaxf) + b, __float_as_int(fmax_));
-        if (tsp) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
-            if (threadIdx.x == 0) tsp[5] = wall_clock64();
-        }
     }
 }
 
@@ -317,7 +297,8 @@ __global__ __launch_bounds__(ROWS * FC_THREADS, ROWS == 2 ? 3 : 4) void fc_row_k
 // eight windows (160 rows) are split into f16 h / l planes in LDS.
 // ---------------------------------------------------------------------------------------------
 #define FC_CW 8                         // windows per chunk
-#define FC_APITCH 72                    // halfs per staged row (64 + 8 pad: conflict-free 16-byte fragment reads)
+#define FC_APITCH 80                    // halfs per staged row (64 + 16 pad = ten 16-byte slots: the four lane groups of a
+                                        // ds_read_b128 each touch sixteen different slots; nine slots gave two-way conflicts)
 
 struct FcGemmArgs {
     const float *Xf; float *Yf;
@@ -580,90 +561,37 @@ void amt_fftconv_layer_destroy_internal(amt_fftconv_layer *L) {
 
 size_t amt_fftconv_freq_floats(int B, int H) { return (size_t)FC_NP * B * H * 64; }
 
-// layout of a window's [289 pairs][H rows][64] block: pair-major (AMT_FC_LAYOUT=0: a GEMM workgroup reads H x 256 contiguous
-// bytes per pair) or row-major (1: a row transform reads and writes 74 KB contiguous, the GEMM 256-byte pieces)
-static void fc_strides(int H, int *sf, int *sh) {
-    static int layout = -1;
-    if (layout < 0) { const char *e = getenv("AMT_FC_LAYOUT"); layout = e ? atoi(e) : FC_DEFAULT_LAYOUT; }
-    if (layout == 1) { *sf = 64; *sh = FC_NP * 64; } else { *sf = H * 64; *sh = 64; }
-}
+// a window's block is [289 pairs][H rows][64]: a GEMM workgroup reads H x 256 contiguous bytes per pair (the row-major
+// alternative, 74 KB contiguous per row transform and 256-byte pieces for the GEMM, measured 2 % slower in round 3)
+static void fc_strides(int H, int *sf, int *sh) { *sf = H * 64; *sh = 64; }
 
-static const size_t FC_ROW_LDS = (size_t)(2 * 16 * FC_PS) * 4 + FC_NF * sizeof(float2);
-static const size_t FC_ROW_LDS1 = (size_t)(16 * FC_PS) * 4 + FC_NF * sizeof(float2);
-static int fc_rows_per_wg() {
-    static int r = 0;
-    if (!r) { const char *e = getenv("AMT_FC_ROWS"); r = (e && atoi(e) == 2) ? 2 : 1; }
-    return r;
-}
-template <bool IN_FREQ>
-static int fc_row_launch(const FcRowArgs &a_, hipStream_t st) {
-    FcRowArgs a = a_;
-    const int rows = a.B * a.H;
-    // AMT_FC_TS=1 (diagnostic): phase split of a row workgroup's life
-    static const bool want_ts = getenv("AMT_FC_TS") != nullptr;
-    static unsigned long long *ts_dev = nullptr;
-    static size_t ts_cap = 0;
-    if (want_ts && IN_FREQ && a.Xf) {
-        if ((size_t)rows > ts_cap) {
-            if (ts_dev) (void)hipFree(ts_dev);
-            AMT_HIP_CHECK(hipMalloc(&ts_dev, (size_t)rows * 6 * sizeof(unsigned long long)));
-            ts_cap = rows;
-        }
-        a.ts = ts_dev;
+static const size_t FC_ROW_LDS = (size_t)(16 * FC_PS) * 4 + FC_NF * sizeof(float2);
+template <bool IN_FREQ, int EPI>
+static int fc_row_launch_t(const FcRowArgs &a, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
+        attr = true;
     }
-    if (fc_rows_per_wg() == 1) {
-        static bool attr1 = false;
-        if (!attr1) {
-            AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS1));
-            if (IN_FREQ)
-                AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<IN_FREQ, 1, IN_FREQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS1));
-            attr1 = true;
-        }
-        static const bool regs_ok = !(getenv("AMT_FC_INREGS") && atoi(getenv("AMT_FC_INREGS")) == 0);
-        if (IN_FREQ && regs_ok && !a.sc && !a.sc1 && !a.out_sp && a.Xf)
-            fc_row_kernel<IN_FREQ, 1, IN_FREQ><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
-        else
-            fc_row_kernel<IN_FREQ, 1><<<rows, FC_THREADS, FC_ROW_LDS1, st>>>(a);
-    } else {
-        fc_row_kernel<IN_FREQ, 2><<<(rows + 1) / 2, 2 * FC_THREADS, FC_ROW_LDS, st>>>(a);
-    }
+    fc_row_kernel<IN_FREQ, EPI><<<a.B * a.H, FC_THREADS, FC_ROW_LDS, st>>>(a);
     AMT_LAUNCH_CHECK();
-    if (a.ts && fc_rows_per_wg() == 1) {
-        AMT_HIP_CHECK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)rows * 6);
-        AMT_HIP_CHECK(hipMemcpy(h.data(), ts_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        double d[5] = {0, 0, 0, 0, 0};
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (int i = 0; i < rows; ++i) {
-            for (int k = 0; k < 5; ++k) d[k] += (double)(h[6 * i + k + 1] - h[6 * i + k]);
-            t0 = std::min(t0, h[6 * i]); t1 = std::max(t1, h[6 * i + 5]);
-        }
-        fprintf(stderr, "fc_row_ts rows %d (sc %d sp %d): load+fft %.2f us, transpose+fft %.2f, ybuf+epilogue %.2f, regather+fft+transpose %.2f, "
-                        "fft+stores %.2f; kernel %.1f us = %.2f lives per slot of 512\n", rows, a.sc || a.sc1 ? 1 : 0, a.out_sp ? 1 : 0,
-                d[0] / rows / 100.0, d[1] / rows / 100.0, d[2] / rows / 100.0, d[3] / rows / 100.0, d[4] / rows / 100.0,
-                (double)(t1 - t0) / 100.0, (double)(t1 - t0) * 512.0 / (d[0] + d[1] + d[2] + d[3] + d[4]));
-    }
     return AMT_OK;
 }
-// persistent row kernels: `per_cu` workgroups per CU (what their registers / LDS allow)
-static int fc_row_grid(int per_cu) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+template <bool IN_FREQ>
+static int fc_row_launch(const FcRowArgs &a, hipStream_t st) {
+    if (!IN_FREQ) return fc_row_launch_t<false, 1>(a, st);
+    if (!a.out_sp) {
+        if (a.sc || a.sc1 || a.amax_out || !a.Xf) return AMT_E_UNSUPPORTED;        // (no layer of the chain: a shortcut sum is always read later)
+        return fc_row_launch_t<true, 1>(a, st);
     }
-    return cus * per_cu;
+    if (a.sc) return fc_row_launch_t<true, 2>(a, st);
+    if (a.sc1) return fc_row_launch_t<true, 3>(a, st);
+    return fc_row_launch_t<true, 4>(a, st);
 }
 
 int amt_fftconv_forward_fft(const amt_fftconv_layer *L, const float *in_sp, size_t in_stride, int B, int H, int W,
                             float *Xf, float *amaxf, hipStream_t st) {
     if (!L || !in_sp || !Xf || !amaxf || W + 15 > FC_NF) return AMT_E_INVALID;
-    static bool attr = false;
-    if (!attr) {
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
-        AMT_HIP_CHECK(hipFuncSetAttribute((const void *)fc_row_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_ROW_LDS));
-        attr = true;
-    }
     AMT_HIP_CHECK(hipMemsetAsync(amaxf, 0, (size_t)B * sizeof(float), st));
     FcRowArgs a{};
     a.in_sp = in_sp; a.in_stride = in_stride; a.Xf = Xf; a.amaxf = amaxf; a.tw = L->tw; a.B = B; a.H = H; a.W = W;

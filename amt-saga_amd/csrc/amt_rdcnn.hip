@@ -1582,7 +1582,15 @@ int amt_rdcnn_profile_read(amt_rdcnn *net, int32_t *desc, double *ms, double *wi
     return AMT_OK;
 }
 
-#define RD_CHUNK 1024
+#define RD_CHUNK_MAX 1024
+// windows per pass through the network (AMT_RD_CHUNK, diagnostic: smaller chunks keep the FFT-domain layers' frequency
+// tensors inside the Infinity Cache at the price of more, smaller launches)
+static int rd_chunk() {
+    static int c = 0;
+    if (!c) { const char *e = getenv("AMT_RD_CHUNK"); c = e ? std::max(1, std::min(atoi(e), RD_CHUNK_MAX)) : RD_CHUNK_MAX; }
+    return c;
+}
+#define RD_CHUNK rd_chunk()
 static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     size_t ma = 0;
     for (const Tower &t : n->towers) ma = std::max(ma, t.max_act);
@@ -1730,7 +1738,7 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                         else { ep.sc = sc; ep.sc_stride = sc_stride; }
                     }
                     rc = amt_fftconv_inverse_epilogue(c.fft, Yf, ep, Bc, H, W, need_sp ? o : nullptr, o_stride,
-                                                      next_fft ? Xf : nullptr, amaxf, amax_o, st);
+                                                      next_fft ? Xf : nullptr, amaxf, next_fft ? nullptr : amax_o, st);
                     if (rc != AMT_OK) return rc;
                     xf_valid = next_fft;
                     wrote_amax = true;
