@@ -112,6 +112,10 @@ PROTOTYPES = {
     'amt_fftconv_destroy': (C.c_int, [vp]),
     'amt_fftconv_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'amt_fftconv_run': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]),
+    'amt_fftpk_create': (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, vp]),
+    'amt_fftpk_destroy': (C.c_int, [vp]),
+    'amt_fftpk_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'amt_fftpk_run': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
     'amt_probe_mfma_f16': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     'amt_rdcnn_profile': (C.c_int, [vp, C.c_int]),
     'amt_rdcnn_profile_read': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, c_int32_p, C.c_int]),

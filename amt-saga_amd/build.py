@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libamt_saga_hip.so')
 SOURCES = ['amt_stft.hip', 'amt_subtract.hip', 'amt_features.hip', 'amt_cqt.hip',
-           'amt_rdcnn.hip', 'amt_loop.hip', 'amt_synth.hip', 'amt_train.hip', 'amt_probe.hip', 'amt_fftconv.hip']
+           'amt_rdcnn.hip', 'amt_loop.hip', 'amt_synth.hip', 'amt_train.hip', 'amt_probe.hip', 'amt_fftconv.hip', 'amt_fftpk.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math',
          '-ffp-contract=off', '-Wall', '-Wno-unused-function',

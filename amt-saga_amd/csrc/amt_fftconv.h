@@ -21,3 +21,14 @@ int amt_fftconv_gemm(const amt_fftconv_layer *L, const float *Xf, const float *a
 int amt_fftconv_inverse_epilogue(const amt_fftconv_layer *L, const float *Yf, const FcEpilogue &ep, int B, int H, int W,
                                  float *out_sp, size_t out_stride, float *Xf_next, float *amaxf_next, float *amax_out,
                                  hipStream_t st);
+
+// ---- packed-image form of the 10 x 64, 64 -> 64 layers (amt_fftpk.hip) ----------------------------------------------
+struct amt_fftpk_layer;
+// kernel: host [4][16][64][64] (Keras layout kh, kw, cin, cout); synchronises the null stream (weights are transformed on the device)
+int amt_fftpk_layer_create_internal(amt_fftpk_layer **out, const float *kernel);
+void amt_fftpk_layer_destroy_internal(amt_fftpk_layer *L);
+size_t amt_fftpk_freq_floats(int B);                                         // floats of one [B][577][128] tensor
+int amt_fftpk_forward_fft(const amt_fftpk_layer *L, const float *in_sp, size_t in_stride, int B, float *Xf, float *amaxf, hipStream_t st);
+int amt_fftpk_gemm(const amt_fftpk_layer *L, const float *Xf, const float *amaxf, int B, float *Yf, hipStream_t st);
+int amt_fftpk_inverse_epilogue(const amt_fftpk_layer *L, const float *Yf, const FcEpilogue &ep, int B, float *out_sp, size_t out_stride,
+                               float *Xf_next, float *amaxf_next, float *amax_out, hipStream_t st);

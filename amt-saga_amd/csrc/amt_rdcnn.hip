@@ -942,6 +942,8 @@ struct ConvOp {
     // 32 -> 32 (4 x 16) layers on images of at most 561 columns; k_host keeps the Keras-layout kernel for that
     std::vector<float> k_host;
     amt_fftconv_layer *fft = nullptr;
+    // packed-image form of the 64 -> 64 (4 x 16) layers on 10 x 64 images (amt_fftpk.hip), same switch
+    amt_fftpk_layer *pk = nullptr;
 };
 struct ProjOp {
     int cin, cout, H, W, ph, pw, HO, WO;
@@ -1305,7 +1307,10 @@ int amt_rdcnn_destroy(amt_rdcnn *net) {
     for (float *p : net->allocs) (void)hipFree(p);
     for (Tower &t : net->towers)
         for (ConvOp &c : t.convs)
+        {
             if (c.fft) amt_fftconv_layer_destroy_internal(c.fft);
+            if (c.pk) amt_fftpk_layer_destroy_internal(c.pk);
+        }
     delete net;
     return AMT_OK;
 }
@@ -1354,8 +1359,9 @@ int amt_rdcnn_create(amt_rdcnn **out, const amt_rdcnn_desc *desc, const float *w
                     amt_rdcnn_destroy(n);
                     return AMT_E_UNSUPPORTED;
                 }
-                if (kh == 4 && kw == 16 && C == 32 && fo == 32 && W + 15 <= 576 && H <= 20)
-                    c.k_host.assign(kern, kern + (size_t)kh * kw * C * fo);      // FFT-domain form, built on demand (mode 3)
+                if ((kh == 4 && kw == 16 && C == 32 && fo == 32 && W + 15 <= 576 && H <= 20) ||
+                    (kh == 4 && kw == 16 && C == 64 && fo == 64 && W == 64 && H == 10))
+                    c.k_host.assign(kern, kern + (size_t)kh * kw * C * fo);      // FFT-domain forms, built on demand (mode 3)
                 const int NT = fo / 32, nch = C / 32, ntap = kh * kw;
                 // small late-stage layers (few output positions per window) cannot fill 256 CUs with
                 // position tiles alone: compute them in 32-channel output slices (blockIdx.y)
@@ -1530,8 +1536,9 @@ int amt_rdcnn_set_mode(amt_rdcnn *net, int mode) {
         // the transformed kernel matrices are computed on the host in float64, once
         for (Tower &t : net->towers)
             for (ConvOp &c : t.convs)
-                if (!c.fft && !c.k_host.empty()) {
-                    const int rc = amt_fftconv_layer_create_internal(&c.fft, c.k_host.data());
+                if (!c.fft && !c.pk && !c.k_host.empty()) {
+                    const int rc = c.cin == 64 ? amt_fftpk_layer_create_internal(&c.pk, c.k_host.data())
+                                               : amt_fftconv_layer_create_internal(&c.fft, c.k_host.data());
                     if (rc != AMT_OK) return rc;
                 }
     }
@@ -1600,7 +1607,10 @@ static size_t ws_floats(const amt_rdcnn *n, int Bc) {
     if (n->mode == 3)
         for (const Tower &t : n->towers)
             for (const ConvOp &c : t.convs)
+            {
                 if (c.fft) fft = std::max(fft, 2 * amt_fftconv_freq_floats(Bc, c.H) + (size_t)Bc + 8);
+                if (c.pk) fft = std::max(fft, 2 * amt_fftpk_freq_floats(Bc) + (size_t)Bc + 8);
+            }
     return (size_t)Bc * (4 * ma + (size_t)((n->flat + 3) & ~3) + (size_t)((n->d.dense_units + 3) & ~3) +
                          (size_t)((n->d.output_classes + 3) & ~3) + (size_t)(n->d.conv_layers + 1)) + 8 + fft;
 }
@@ -1741,6 +1751,26 @@ int amt_rdcnn_forward(const amt_rdcnn *net, const float *const *x, int B, float 
                                                       next_fft ? Xf : nullptr, amaxf, next_fft ? nullptr : amax_o, st);
                     if (rc != AMT_OK) return rc;
                     xf_valid = next_fft;
+                    wrote_amax = true;
+                } else if (net->mode == 3 && c.pk) {
+                    // packed-image form of a 10 x 64, 64 -> 64 layer: the same chaining, one GEMM row per window
+                    float *Xf = amax + (size_t)(d.conv_layers + 1) * Bc + 8;
+                    Xf = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(Xf) + 15) & ~(uintptr_t)15);
+                    float *Yf = Xf + amt_fftpk_freq_floats(Bc);
+                    float *amaxf = Yf + amt_fftpk_freq_floats(Bc);
+                    int rc = AMT_OK;
+                    if (!xf_valid) rc = amt_fftpk_forward_fft(c.pk, cur, cur_stride, Bc, Xf, amaxf, st);
+                    if (rc == AMT_OK) rc = amt_fftpk_gemm(c.pk, Xf, amaxf, Bc, Yf, st);
+                    if (rc != AMT_OK) return rc;
+                    const bool next_pk = i + 1 < L && !c.pool_after && tw.convs[i + 1].pk;
+                    const bool need_sp = !next_pk || c.residual;
+                    FcEpilogue ep;
+                    ep.s1 = c.s1; ep.t1 = c.t1;
+                    if (c.residual) { ep.s2 = c.s2; ep.t2 = c.t2; ep.sc = sc; ep.sc_stride = sc_stride; }
+                    rc = amt_fftpk_inverse_epilogue(c.pk, Yf, ep, Bc, need_sp ? o : nullptr, o_stride, next_pk ? Xf : nullptr, amaxf,
+                                                    next_pk ? nullptr : amax_o, st);
+                    if (rc != AMT_OK) return rc;
+                    xf_valid = next_pk;
                     wrote_amax = true;
                 } else {
                     ConvParams cp{cur, cur_stride, o, o_stride, sc, sc_stride, c.w, c.s1, c.t1,

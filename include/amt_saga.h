@@ -395,6 +395,24 @@ int amt_fftconv_run(const amt_fftconv_layer *layer, const float *in, const float
                     float *out, void *workspace, size_t workspace_bytes, int repeat_gemm, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * The same layer kind on the 10 x 64 images behind the first pooling of the timing classifier
+ * (timing_classifier.py:13-36; Conv2D(64, (4, 16), 'same') + BatchNormalization + sigmoid (+ Add + BatchNormalization),
+ * RDCNN.py:186-198) in the packed-image FFT-domain form (amt_fftpk.hip): the whole image is one 1152-point sequence per
+ * channel pair, one 128 x 128 GEMM per frequency pair with the windows as rows.  Stand-alone entry for the parity tests
+ * and the layer microbenchmark; inside amt_rdcnn_forward the same kernels run chained (conv mode 3).
+ *   kernel_host [4][16][64][64]; s1, t1, s2, t2 [64]; in / shortcut / out: device [B][10][64][64];
+ *   chain: extra applications of the layer (BN + sigmoid, no shortcut) with the hand-over in the frequency domain before the
+ *   final one; repeat_gemm: the final GEMM launched that many times (timing).
+ * ------------------------------------------------------------------------ */
+typedef struct amt_fftpk_layer amt_fftpk_layer;
+int amt_fftpk_create(amt_fftpk_layer **layer, const float *kernel_host, const float *s1, const float *t1,
+                     const float *s2, const float *t2);
+int amt_fftpk_destroy(amt_fftpk_layer *layer);
+size_t amt_fftpk_workspace_bytes(int B);
+int amt_fftpk_run(const amt_fftpk_layer *layer, const float *in, const float *shortcut, int B, float *out,
+                  void *workspace, size_t workspace_bytes, int chain, int repeat_gemm, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Measurement probe (no reference counterpart; bench.py's roofline object).  Sustained rate of back-to-back
  * v_mfma_f32_16x16x32_f16 on register operands with `waves_per_simd` waves per SIMD on every CU, `iters` x 8
  * MFMAs per wave and launch, best of `launches`; random_operands != 0: random non-zero f16 operands (the rate

@@ -85,14 +85,16 @@ class LoopOracle:
 
     def _argmax(self, pr, name='instrument', col=3):
         pr = np.asarray(pr)
-        v = int(np.argmax(pr))
-        top = np.sort(pr)[-2:]
-        margin = float(top[1] - top[0])
+        order = np.argsort(-pr, kind='stable')               # first maximum first, as np.argmax
+        v, runner_up = int(order[0]), int(order[1]) if len(pr) > 1 else int(order[0])
+        margin = float(pr[v] - pr[runner_up])
         forced = False
         if self._force is not None:
+            # teacher forcing at a near-tie of the two LARGEST probabilities only: the other implementation may name the
+            # runner-up class when it lies within the band of the winner, and no other class
             ev, band = self._force
             g = int(ev[self._it][col])
-            if g != v and margin < band.get(name, 0.0) and 0 <= g < len(pr) and pr[v] - pr[g] < band.get(name, 0.0):
+            if g != v and g == runner_up and margin < band.get(name, 0.0):
                 v, forced = g, True
         self.decisions.append((name, self._it, pr.copy(), margin, v, forced))
         return v

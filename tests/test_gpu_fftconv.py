@@ -66,3 +66,50 @@ def test_fftconv_layer_vs_numpy(B, H, W, residual):
     print('fftconv %dx%dx%d residual=%s: e_gpu %.3g  e_cpu(f32 direct) %.3g' % (B, H, W, residual, e_gpu, e_cpu))
     assert e_gpu < 1e-5, e_gpu
     assert e_gpu <= 2.5 * e_cpu + 2.4e-7, (e_gpu, e_cpu)
+
+
+@pytest.mark.parametrize('B,residual,chain', [(3, True, 0), (9, False, 0), (2, True, 1), (70, False, 2)])
+def test_fftpk_layer_vs_numpy(B, residual, chain):
+    """The packed-image form of a 10 x 64, 64 -> 64 (4 x 16) layer (amt_fftpk.hip: the whole image as one 1152-point
+    sequence per channel pair, one 128 x 128 GEMM per frequency pair) against the float64 direct convolution, under the
+    bar of the other arithmetics; chain > 0: the layer applied chain + 1 times with the hand-over in the frequency domain
+    (register epilogue, re-zeroed gaps), B = 70: more than one GEMM chunk, ragged."""
+    import torch
+    from amt_saga import _lib
+    lib = _lib.load()
+    H, W, Cn = 10, 64, 64
+    rng = np.random.default_rng(B * 100 + chain)
+    a = rng.random((B, H, W, Cn)).astype(np.float32)
+    a[0] *= np.float32(3.0)
+    k = (rng.standard_normal((4, 16, Cn, Cn)) * 0.04).astype(np.float32)
+    s1 = rng.uniform(0.5, 2.0, Cn).astype(np.float32); t1 = rng.uniform(-1, 1, Cn).astype(np.float32)
+    s2 = rng.uniform(0.5, 2.0, Cn).astype(np.float32); t2 = rng.uniform(-1, 1, Cn).astype(np.float32)
+    sc = rng.random((B, H, W, Cn)).astype(np.float32) if residual else None
+
+    def ref(dtype):
+        v = a
+        for _ in range(chain):
+            v = _layer(v, k, s1, t1, None, s2, t2, dtype)
+        return _layer(v, k, s1, t1, sc, s2, t2, dtype)
+    ref64, ref32 = ref(np.float64), ref(np.float32)
+    h = C.c_void_p()
+    fp = lambda x: x.ctypes.data_as(C.c_void_p)
+    _lib.check(lib.amt_fftpk_create(C.byref(h), fp(k), fp(s1), fp(t1), fp(s2) if residual else None, fp(t2) if residual else None))
+    try:
+        ad = torch.from_numpy(a).cuda()
+        scd = torch.from_numpy(sc).cuda() if residual else None
+        out = torch.empty_like(ad)
+        need = lib.amt_fftpk_workspace_bytes(B)
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device='cuda')
+        _lib.check(lib.amt_fftpk_run(h, ad.data_ptr(), scd.data_ptr() if residual else None, B, out.data_ptr(),
+                                     ws.data_ptr(), need, chain, 1, None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    finally:
+        lib.amt_fftpk_destroy(h)
+    scale = np.abs(ref64).max()
+    e_gpu = np.abs(got - ref64).max() / scale
+    e_cpu = np.abs(ref32 - ref64).max() / scale
+    print('fftpk B=%d residual=%s chain=%d: e_gpu %.3g  e_cpu(f32 direct) %.3g' % (B, residual, chain, e_gpu, e_cpu))
+    assert e_gpu < 1e-5, e_gpu
+    assert e_gpu <= 2.5 * e_cpu + 2.4e-7, (e_gpu, e_cpu)
