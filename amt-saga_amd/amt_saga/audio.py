@@ -182,7 +182,10 @@ class AudioBatch:
         a.relu = int(bool(relu))
         a.overkill_factor = float(overkill_factor)
         fm = self._fmax
-        if span and relu and fm is not None and fm[1] == self.mag.data_ptr() and fm[0].shape == (B, T):
+        # the cached maxima describe `mag` only while it is the same tensor AND unedited since (the key holds its address
+        # and torch's in-place version counter; the kernels behind this class write through raw pointers, which the counter
+        # does not see -- those writers are this class's own and refresh or drop the cache themselves)
+        if span and relu and fm is not None and fm[1] == (self.mag.data_ptr(), self.mag._version) and fm[0].shape == (B, T):
             _lib.check(self.lib.amt_subtract_span(C.byref(a), ptr(fm[0]), int(guess_mag.shape[1]), stream_ptr()))
         else:
             self._fmax = None
@@ -206,7 +209,7 @@ class AudioBatch:
             _lib.check(self.lib.amt_compress_bands_fmax(
                 ptr(self.mag), B, T, self.F, self.ldf, T * self.ldf, ptr(edges), bands, ptr(ref),
                 None, ptr(out), target, ptr(fm), stream_ptr()))
-            self._fmax = (fm, self.mag.data_ptr())
+            self._fmax = (fm, (self.mag.data_ptr(), self.mag._version))
             return out
         _lib.check(self.lib.amt_compress_bands(
             ptr(self.mag), B, T, self.F, self.ldf, T * self.ldf, ptr(edges), bands, ptr(ref),

@@ -46,6 +46,12 @@ def init(backend=None, force=False):
     return rank, world, local
 
 
+def world_size_seen():
+    """The size of the process group as torch.distributed reports it after init (1 without a group): what bench.py
+    prints as `rccl_world`, so that a scaling record shows how many ranks really ran."""
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def shard_range(n_windows, rank, world):
     """Contiguous block of ceil(B/G) windows per rank; the last
     ranks may get fewer (or none)."""

@@ -356,6 +356,11 @@ typedef _Float16 cq_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cq_h4 __attribute__((ext_vector_type(4)));
 typedef float cq_f4 __attribute__((ext_vector_type(4)));
 
+#ifdef AMT_CQM_DIAG
+#define CQM_DBG(a) ((a).debug)
+#else
+#define CQM_DBG(a) 0
+#endif
 struct CqmArgs {
     const float *wave; size_t wave_stride;
     const unsigned int *phase_inc; const int *length;
@@ -363,7 +368,8 @@ struct CqmArgs {
     const float *amax;                  // [B] max |x| of each window
     unsigned int *out_max;              // [B] float bits, zeroed by the caller
     int L, H, hshift, T, n_bins, nblk, q, r, KS;
-    int debug;                          // AMT_CQM_DEBUG (timing breakdown only): 1 no epilogue, 2 no MFMAs, 4 no commit
+    int debug;                          // diagnostic builds only (-DAMT_CQM_DIAG + env AMT_CQM_DEBUG: 1 no epilogue, 2 no MFMAs,
+                                        // 4 no commit -- a timing breakdown with WRONG results); the product build ignores it
 };
 
 // table: column col of group g = bin g * CQM_BINS + col / 18, component col % 18 = set * 6 + kind * 2 + part
@@ -533,10 +539,10 @@ __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
     fetch(0);
     const int fr = (lane & 15) * 32 + 8 * (lane >> 4);               // fragment offset inside a [16][32] tile (halfs)
     for (int c = 0; c < KS; ++c) {
-        if (!(a.debug & 4)) commit(c);
+        if (!(CQM_DBG(a) & 4)) commit(c);
         __syncthreads();
         if (c + 1 < KS) fetch(c + 1);
-        if (a.debug & 2) continue;
+        if (CQM_DBG(a) & 2) continue;
         const _Float16 *ap = a_priv + (size_t)wid * (2 * 64 * 32);
         const _Float16 *sp = a_shr + (size_t)(c & 1) * (2 * 32 * 32);
         const _Float16 *bp = b_lds + (size_t)(c & 1) * (2 * 128 * 32);
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void cqt_max_mfma_kernel(CqmArgs a) {
         }
     }
     __syncthreads();                                 // every wave is done with the operand buffers: reuse them below
-    if (a.debug & 1) {                               // timing breakdown only
+    if (CQM_DBG(a) & 1) {                            // timing breakdown only
         float v = 0.f;
         for (int i = 0; i < (Q > 0 ? Q : 1); ++i) for (int n = 0; n < CQM_NT; ++n) v += acc[i][n].x;
         if (v == 12345.f) atomicMax(a.out_max + b, 1u);
@@ -952,7 +958,10 @@ extern "C" int amt_cqt_window_max_mfma(const float *wave, int B, int L, size_t w
     a.wave = wave; a.wave_stride = wave_stride; a.phase_inc = phase_inc; a.length = length;
     a.table = (const _Float16 *)table; a.amax = amax_scratch; a.out_max = (unsigned int *)out_max;
     a.L = L; a.H = hop; a.T = 1 + L / hop; a.n_bins = n_bins; a.KS = hop >> 5;
+    a.debug = 0;
+#ifdef AMT_CQM_DIAG
     { const char *e = getenv("AMT_CQM_DEBUG"); a.debug = e ? atoi(e) : 0; }
+#endif
     const int groups = (n_bins + CQM_BINS - 1) / CQM_BINS;
     kern<<<dim3(groups, B), 512, lds, st>>>(a);
     AMT_LAUNCH_CHECK();

@@ -132,6 +132,9 @@ extern "C" int amt_subtract_span(const amt_subtract_args *args, float *frame_max
     if (a.normalize && (!a.resid_max || !a.guess_max)) return AMT_E_INVALID;
     if (!a.guess_frames && a.guess_frames_all < 0) return AMT_E_INVALID;
     if (span_cap <= 0) return AMT_E_INVALID;                  // >= every window's guess_frames (the guess tensor's frame count)
+    // a uniform frame count beyond the launch's frame grid would be left unsubtracted (per-window counts live on the
+    // device: their bound is the caller's contract, span_cap = the guess tensor's frame count)
+    if (!a.guess_frames && a.guess_frames_all > span_cap) return AMT_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int cap = span_cap < a.T ? span_cap : a.T;
     subtract_span_kernel<<<dim3((cap + 3) / 4, a.B), 256, 0, st>>>(a, frame_max);

@@ -1380,7 +1380,10 @@ int amt_trainer_step(amt_trainer *t, const float *const *x, const float *y, int 
                 bnf_bwd_apply_kernel<<<nwg, 256, 0, st>>>(gout, a, in.v, o.bmu, o.binv, t->params[o.p0].w, t->params[o.p1].g,
                                                           t->params[o.p0].g, 1.0f / (float)M, M, o.Cout, in.H * in.W, acc, dst,
                                                           t->red2, in.gam_slot);
+                // red2 now holds THIS launch's column partials: valid as the bias gradient of the convolution in front only when
+                // dz was written, not accumulated; any partials another convolution was still waiting for are gone either way
                 if (!acc) { in.gam = in.gam_slot; t->colsum_of = o.in0; t->colsum_nwg = nwg; }
+                else t->colsum_of = -1;
                 break;
             }
             // generic path: dy -> scratch, two column sums, dz

@@ -303,13 +303,14 @@ def main():
     # split-fp16 class -- and the FFT-domain layers get their own object (roofline_fft: bound by the HBM traffic of the
     # frequency tensors)
     fft_keys = [k for k in by_class if conv_mode == 3 and k[:4] == (4, 16, 32, 32) and k[5] + 15 <= 576 and k[4] <= 20]
-    direct = {k: v for k, v in by_class.items() if k not in fft_keys} or by_class
+    pk_keys = [k for k in by_class if conv_mode == 3 and k == (4, 16, 64, 64, 10, 64)]       # packed-image form (amt_fftpk.hip)
+    direct = {k: v for k, v in by_class.items() if k not in fft_keys and k not in pk_keys} or by_class
     dom_key = max(direct, key=lambda k: direct[k]['ms'])
     dom = by_class[dom_key]
     conv_ms_total = sum(a['ms'] for a in by_class.values())
     achieved_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
     arith = 2 if conv_mode == 3 else conv_mode
-    split = arith >= 1 and dom_key[2] <= 64
+    split = arith == 2 or (arith == 1 and dom_key[2] <= 64)       # (the 128-channel layers run split-fp16 too; split-bf16 stops at 64)
     nmf = 3 if arith == 2 else 6                           # MFMAs per f32-equivalent product block
     # split modes: every algorithmic f32 MAC costs nmf f16 / bf16 MFMA MACs, so the MFMA roof for the
     # ALGORITHMIC flops of this kernel is the dense 16-bit peak / nmf
@@ -350,6 +351,27 @@ def main():
                             ms_per_layer_per_1024_windows=round(fa['ms'] / (fa['windows'] / 1024.0), 3),
                             direct_form_equivalent_tflops=round(fa['flops'] / (fa['ms'] * 1e-3) / 1e12, 1),
                             share_of_conv_time=round(fa['ms'] / conv_ms_total, 3))
+    roofline_pk = None
+    if pk_keys:
+        pa = by_class[pk_keys[0]]
+        # one chained layer and window: read Xf, write Yf (GEMM); read Yf, write Xf (inverse + epilogue + forward):
+        # 4 x 577 x 128 x 4 B; every second layer also reads a shortcut and writes its spatial output (10 x 64 x 64 x 4 B each)
+        per_layer_window = 4 * 577 * 128 * 4 + 10 * 64 * 64 * 4
+        gbs = per_layer_window * pa['windows'] / (pa['ms'] * 1e-3) / 1e9
+        pk_traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            per_w = lambda k: pj[k]['hbm_bytes_per_launch'] / pj[k]['windows_per_launch']
+            n0, n1 = pj['pk_row']['dispatches_in_class'], pj['pk_row_inregs']['dispatches_in_class']
+            pk_traffic = int((per_w('pk_gemm') + (per_w('pk_row') * n0 + per_w('pk_row_inregs') * n1) / (n0 + n1)) * min(B, 1024))
+        except Exception:
+            pk_traffic = None
+        roofline_pk = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                           traffic=pk_traffic, kernel='pk_gemm_kernel + pk_row_kernel<true> per layer (amt_fftpk.hip), 10x64 64->64 (4x16)',
+                           algorithmic_bytes_per_layer_window=per_layer_window,
+                           ms_per_layer_per_1024_windows=round(pa['ms'] / (pa['windows'] / 1024.0), 3),
+                           direct_form_equivalent_tflops=round(pa['flops'] / (pa['ms'] * 1e-3) / 1e12, 1),
+                           share_of_conv_time=round(pa['ms'] / conv_ms_total, 3))
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     pmc = {}
@@ -359,6 +381,8 @@ def main():
             # scripts/make_pmc_traffic.py), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
             pmc = json.load(open(tf))
             t = pmc.get(('conv_f16x3' if arith == 2 else 'conv_bf16x6') if split else 'conv_mfma')
+            if t and conv_mode == 3 and ('<%d, %d, %d,' % dom_key[:3]) not in t.get('kernel', ''):
+                t = None                 # the file's direct-conv class is not the one this run reports
             if t and t.get('windows_per_launch'):
                 traffic = int(t['hbm_bytes_per_launch'] * min(B, 1024) / t['windows_per_launch'])
         except Exception:
@@ -378,13 +402,24 @@ def main():
         sustained = {'sustained_f16_mfma_tflops_measured': round(tf_.value, 1),
                      'sustained_probe': 'amt_probe_mfma_f16(2 waves/SIMD, random operands), %.0f ms launch, this run' % ms_.value,
                      'executed_vs_sustained': round(achieved_tf * nmf / tf_.value, 3)}
-    from_profiles = None
+    # profiles/pmc_derived.json: kernel name -> counters of a separate --pmc pass (scripts/pmc_conv.sh, pmc_fftconv.sh); an
+    # object only carries the entry of the kernel it names
+    derived = {}
     pd = os.path.join(ROOT, 'profiles', 'pmc_derived.json')
     if os.path.exists(pd):
         try:
-            from_profiles = json.load(open(pd))
+            derived = json.load(open(pd))
         except Exception:
-            from_profiles = None
+            derived = {}
+
+    def derived_for(*patterns):
+        out = {k: v for k, v in derived.items() if isinstance(v, dict) and any(pt in k for pt in patterns)}
+        return out or None
+    from_profiles = derived_for('conv_f16x3s_kernel<%d, %d, %d,' % dom_key[:3]) if (split and arith == 2) else None
+    if roofline_fft:
+        roofline_fft['from_profiles'] = derived_for('fc_gemm_kernel', 'fc_row_kernel<true')
+    if roofline_pk:
+        roofline_pk['from_profiles'] = derived_for('pk_gemm_kernel', 'pk_row_kernel<true')
     roofline = dict(bound='mfma', achieved=round(achieved_tf, 2), peak=peak_tf, unit='TFLOP/s',
                     frac=round(achieved_tf / peak_tf, 4), traffic=traffic, kernel=kname,
                     peak_note=('dense bf16/f16 MFMA peak 2500 / %d MFMAs per f32-equivalent product block' % nmf
@@ -394,7 +429,7 @@ def main():
                     vs_f32_mfma_peak=round(achieved_tf / MFMA_F32_PEAK_TF, 3),
                     share_of_conv_time=round(dom['ms'] / conv_ms_total, 3),
                     conv_ms_per_step=round(conv_ms_total / args.steps, 2),
-                    from_profiles=from_profiles)
+                    from_profiles=from_profiles, profiles_provenance=derived.get('_provenance'))
     # ---- the north star's HBM pair: only the bytes the step consumes ------------------------
     F, T, ldf = p.N // 2 + 1, p.timing_frames, (p.N // 2 + 1 + 3) & ~3
     stft_ms = sum(e0.elapsed_time(e1) for tag, e0, e1, _ in ev_pairs if tag == 'stft')
@@ -534,7 +569,15 @@ def main():
             # mode 3 is reported as roofline_mfma
             'roofline': roofline_fft if (roofline_fft and roofline_fft['share_of_conv_time'] > roofline['share_of_conv_time']) else roofline,
             'roofline_mfma': roofline if (roofline_fft and roofline_fft['share_of_conv_time'] > roofline['share_of_conv_time']) else None,
+            'roofline_pk': roofline_pk,
             'roofline_stft': roofline_stft, 'cpu_baseline': cpu,
+            # what `value` is: the bench contract's rate -- inputs resident in HBM when the clock starts, event all-gather
+            # inside.  SURVEY 8d words the metric with the host -> HBM copy of the audio inside: that figure is
+            # value_h2d_overlapped (copy of batch i + 1 under the compute of batch i, TranscriptionLoop.run_stream) /
+            # value_h2d_inclusive (serial copy)
+            'value_definition': 'inputs resident in HBM, event all-gather inside the timed region (bench contract); the '
+                                'PCIe-inclusive rates of SURVEY 8d are value_h2d_overlapped / value_h2d_inclusive',
+            'rccl_world': adist.world_size_seen(), 'windows_per_gpu': [B] * world,
             'prepare_ms': round(prepare_ms, 1),
             'events_checksum': int(events.to(torch.int64).sum().item()),
             'distinct_decisions': {k: int(torch.unique(events[:, c]).numel())

@@ -19,12 +19,12 @@ cp /tmp/prof_ks/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 python3 $R/scripts/summarize_trace.py /tmp/prof_ks $OUT/kernel_trace_summary.csv >> $OUT/ks.err 2>&1
 # counters in their own passes, nothing but --pmc (+ kernel names come with the counter csv)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -- \
-    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline --no-extras > $OUT/bench_pmc_fetch.json 2> $OUT/pf.err
+    python3 $R/bench.py --steps 1 --warmup 0 --windows 1024 --no-cpu-baseline --no-extras > $OUT/bench_pmc_fetch.json 2> $OUT/pf.err
 python3 $R/scripts/summarize_pmc.py /tmp/prof_f FETCH_SIZE $OUT/pmc_fetch.csv >> $OUT/pf.err 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -- \
-    python3 $R/bench.py --steps 1 --warmup 0 --windows 256 --no-cpu-baseline --no-extras > $OUT/bench_pmc_write.json 2> $OUT/pw.err
+    python3 $R/bench.py --steps 1 --warmup 0 --windows 1024 --no-cpu-baseline --no-extras > $OUT/bench_pmc_write.json 2> $OUT/pw.err
 python3 $R/scripts/summarize_pmc.py /tmp/prof_w WRITE_SIZE $OUT/pmc_write.csv >> $OUT/pw.err 2>&1
-python3 $R/scripts/make_pmc_traffic.py $OUT/pmc_fetch.csv $OUT/pmc_write.csv 256 $TAG > $OUT/pmc_traffic.log 2>&1
+python3 $R/scripts/make_pmc_traffic.py $OUT/pmc_fetch.csv $OUT/pmc_write.csv 1024 $TAG > $OUT/pmc_traffic.log 2>&1
 cp $R/profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # C5's per-GPU shard: 2048 windows, all heads, 5 iterations (kernel trace only)
 rm -rf /tmp/prof_c5

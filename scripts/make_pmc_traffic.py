@@ -16,15 +16,18 @@ import csv, json, os, subprocess, sys
 
 fetch, write, windows = sys.argv[1], sys.argv[2], int(sys.argv[3])
 tag = sys.argv[4] if len(sys.argv) > 4 else ''
-FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 32, false',
+FAMILIES = {'conv_f16x3': 'conv_f16x3s_kernel<4, 16, 128, true',        # the largest direct class of a mode-3 step (5 x 8 images)
             'conv_mfma': 'conv_mfma_kernel<4, 16, 32, 32',
             'stft': 'stft_mag_kernel<2048, true', 'stft_mag_only': 'stft_mag_kernel<2048, false',
             'subtract': 'subtract_kernel', 'subtract_span': 'subtract_span_kernel', 'compress_bands': 'compress_bands_kernel',
             'cqt_window_max': 'cqt_blocks_kernel<false', 'cqt_window_max_mfma': 'cqt_max_mfma_kernel',
             # conv mode 3: the FFT-domain layers (fc_row_kernel<true> = inverse + epilogue [+ forward]: its launches of a
             # chain differ in what they read and write -- shortcut, spatial output -- and are averaged)
-            'fc_gemm': 'fc_gemm_kernel', 'fc_row': 'fc_row_kernel<true, 1, false', 'fc_row_inregs': 'fc_row_kernel<true, 1, true',
-            'fc_row_first': 'fc_row_kernel<false'}
+            'fc_gemm': 'fc_gemm_kernel', 'fc_row': 'fc_row_kernel<true, 2', 'fc_row_inregs': 'fc_row_kernel<true, 1',
+            'fc_row_first': 'fc_row_kernel<false',
+            # the packed-image form of the 10 x 64 layers (amt_fftpk.hip)
+            'pk_gemm': 'pk_gemm_kernel', 'pk_row': 'pk_row_kernel<true, 2', 'pk_row_inregs': 'pk_row_kernel<true, 1',
+            'pk_row_first': 'pk_row_kernel<false'}
 
 
 def load(path):

@@ -70,3 +70,64 @@ def test_rccl_world1_all_gather_of_device_events(tmp_path):
     key = plain[:, 0].astype(np.int64) * (1 << 20) + plain[:, 1]
     assert np.array_equal(got, plain[np.argsort(key, kind='stable')])
     assert got.shape == (12, 7) and np.array_equal(np.unique(got[:, 0]), np.arange(6))
+
+
+WORKER2 = r'''
+import os, sys, json
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'amt-saga_amd')]
+import numpy as np, torch
+import torch.distributed as tdist
+from amt_saga import dist as adist
+rank, world, local = adist.init()                              # before anything else touches the GPU in this process
+assert world == 2 and tdist.get_backend() == 'nccl' and adist.world_size_seen() == 2
+from amt_saga import synth
+from amt_saga.hyperparams import Hyperparams
+from amt_saga.loop import TranscriptionLoop
+p = Hyperparams(N=2048, window_size_note_time=1)
+B, iters = 12, 2
+lo, hi = (0, 7) if rank == 0 else (7, 12)                      # ragged shards 7 + 5: the padded all-gather path
+lp = TranscriptionLoop(p, heads=('timing', 'pitch', 'velocity'), iters=iters).setup_device()
+L = p.H * (p.timing_frames - 1)
+wave, _ = synth.make_windows(B, L, seed=5, notes_per_window=(1, 3), device='cuda')   # every rank renders all, runs its shard
+events, b = lp.run(wave[lo:hi].contiguous(), window0=lo)
+adist.barrier()
+out = adist.gather_events(events, n_total=B * iters)
+t = adist.max_over_ranks(float(rank + 1))
+adist.barrier()
+if rank == 0:
+    np.save(%(out)r, out.numpy())
+    print(json.dumps(dict(max=t, world=adist.world_size_seen())))
+adist.shutdown()
+'''
+
+
+def test_rccl_world2_ragged_shards_equal_single_process(tmp_path):
+    """Two ranks on two GPUs over RCCL (fresh child processes, created before any GPU call), ragged shards 7 + 5: the
+    gathered events must equal the single-process run of the same 12 windows.  Skips on a one-GPU box -- the driver's
+    multi-GPU node is where it runs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL world size 2)')
+    from amt_saga import synth
+    from amt_saga.hyperparams import Hyperparams
+    from amt_saga.loop import TranscriptionLoop
+    out = str(tmp_path / 'ev2.npy')
+    script = tmp_path / 'worker2.py'
+    script.write_text(WORKER2 % dict(root=ROOT, out=out))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.pop('AMT_DIST_BACKEND', None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p_.communicate(timeout=900) for p_ in procs]
+    assert all(p_.returncode == 0 for p_ in procs), [o[1][-3000:] for o in outs]
+    info = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert info == dict(max=2.0, world=2)
+    p = Hyperparams(N=2048, window_size_note_time=1)
+    lp = TranscriptionLoop(p, heads=('timing', 'pitch', 'velocity'), iters=2).setup_device()
+    wave, _ = synth.make_windows(12, p.H * (p.timing_frames - 1), seed=5, notes_per_window=(1, 3), device='cuda')
+    plain = lp.run(wave)[0].reshape(-1, 7).cpu().numpy()
+    key = plain[:, 0].astype(np.int64) * (1 << 20) + plain[:, 1]
+    assert np.array_equal(np.load(out), plain[np.argsort(key, kind='stable')])
