@@ -68,7 +68,9 @@ class TranscriptionLoop:
             from . import sf2 as _sf2
             soundfont = _sf2.SoundFont(soundfont)
         self.soundfont = soundfont
-        self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
+        # timing_end on a second HIP stream under timing_start (the two networks read the same features and are independent:
+        # the second stream fills the tails of the first one's small launches); AMT_TIMING_STREAMS=1: one stream
+        self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '2'))
         # the subtraction on the guess's frames only (amt_subtract_span): the residual is a magnitude spectrogram (>= 0) and
         # the timing features' compress_bands pass leaves the per-frame maxima on the way; AMT_SUBTRACT_SPAN=0: whole windows
         self.span_subtract = os.environ.get('AMT_SUBTRACT_SPAN', '1') != '0'

@@ -12,8 +12,8 @@ RDCNN heads -> note decision -> guess lookup -> subtract] -> event gather.
 Weak scaling: every rank processes the same number of windows.
 
 Prints ONE JSON line on rank 0 with the driver contract plus
-  roofline      dominant kernel(s) of the step, timed with HIP events recorded around every conv layer inside the timed
-                region: conv mode 3 (default) -- the FFT-domain form of the timing heads' 4 x 16 layers (fc_gemm_kernel +
+  roofline      dominant kernel(s) of the step, timed with HIP events recorded around every conv layer in the one-stream
+                measurement pass: conv mode 3 (default) -- the FFT-domain form of the timing heads' 4 x 16 layers (fc_gemm_kernel +
                 fc_row_kernel per layer): algorithmic HBM bytes of the frequency tensors / time; modes 0-2 -- the
                 largest direct convolution class on the matrix pipe: algorithmic TFLOP/s
   roofline_mfma (mode 3) the largest DIRECT split-fp16 convolution class, as `roofline` reports it in mode 2
@@ -23,7 +23,10 @@ Prints ONE JSON line on rank 0 with the driver contract plus
                 and a multiprocessing Pool (one window per task, one BLAS thread each: the reference's
                 worker model, training.py:623-630)
   value_f32_mfma          the same step with the strict-f32 convolutions (--conv-mode 0), same run
-  value_timing_on_two_streams   the same step with timing_end on a second stream (AMT_TIMING_STREAMS=2)
+  value_one_stream_profiled     the measurement pass behind the roofline objects: the same steps with both timing networks
+                          on ONE stream (a kernel's duration is then that of a kernel that owns the chip) and HIP events
+                          around every conv layer / STFT / subtract launch, outside the timed region.  `value` itself runs
+                          timing_end on a second stream under timing_start (TranscriptionLoop.timing_streams = 2, the default)
   value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
                           (SURVEY 8d defines the metric including that copy; never `value`)
   value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
@@ -256,10 +259,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # ---- the timed region: the product as it runs (timing_end on a second stream under timing_start) -----------------
+    dt, (events, last) = timed_steps(args.steps, step)
+    value = B * world * args.steps / dt
+    # ---- per-kernel measurement pass, OUTSIDE the timed region: the same steps on ONE stream, so that a kernel's duration
+    # (the rooflines' denominator) is that of a kernel that owns the chip, with HIP events around every conv layer and
+    # around the STFT / subtract launches (events on the launch stream = torch's current stream)
+    streams_default = loop.timing_streams
+    loop.timing_streams = 1
+    step()
     for n in prof_nets:
         n.profile(True)
         n.profile_read(reset=True)
-    # STFT / subtract kernel timing with events on the launch stream (torch's current stream)
     from amt_saga.audio import AudioBatch
     ev_pairs = []
     orig_stft, orig_sub = AudioBatch.stft, AudioBatch.subtract
@@ -281,10 +292,9 @@ def main():
             return r
         return w
     AudioBatch.stft, AudioBatch.subtract = timed(orig_stft, 'stft'), timed(orig_sub, 'subtract')
-
-    dt, (events, last) = timed_steps(args.steps, step)
+    dt_one, _ = timed_steps(args.steps, step)
     AudioBatch.stft, AudioBatch.subtract = orig_stft, orig_sub
-    value = B * world * args.steps / dt
+    loop.timing_streams = streams_default
 
     # ---- roofline of the dominant kernel (HIP events around every conv launch) -------------
     rows = []
@@ -500,17 +510,6 @@ def main():
         kp = max(1, min(args.steps, 5))
         dtp, _ = timed_steps(kp, step_fresh)
         extras['value_prepare_inclusive'] = round(B * world * kp / dtp, 2)
-        # (1b) timing_end on a second stream under timing_start (TranscriptionLoop.timing_streams = 2, opt-in: it fills
-        # the tails of the small-image launches, but two kernels then share the chip and a kernel's own duration --
-        # the roofline's denominator -- is no longer defined; so it is an extra leg, not the default)
-        if 'timing' in wl['heads'] and loop.timing_streams == 1:
-            loop.timing_streams = 2
-            step()
-            kt = max(1, min(args.steps, 3))
-            dtt, _ = timed_steps(kt, step)
-            extras['value_timing_on_two_streams'] = round(B * world * kt / dtt, 2)
-            loop.timing_streams = 1
-            step()
         # (2) host -> HBM copy of the batch's audio inside the timed region (pinned host memory, one copy
         # per step on the launch stream, no overlap with compute)
         host = torch.empty((B, L), dtype=torch.float32).pin_memory()
@@ -578,6 +577,10 @@ def main():
             'value_definition': 'inputs resident in HBM, event all-gather inside the timed region (bench contract); the '
                                 'PCIe-inclusive rates of SURVEY 8d are value_h2d_overlapped / value_h2d_inclusive',
             'rccl_world': adist.world_size_seen(), 'windows_per_gpu': [B] * world,
+            'timing_streams': streams_default,
+            # the measurement pass behind the roofline objects: the same steps on one stream with HIP events around every
+            # conv layer / STFT / subtract launch (outside the timed region)
+            'value_one_stream_profiled': round(B * world * args.steps / dt_one, 2),
             'prepare_ms': round(prepare_ms, 1),
             'events_checksum': int(events.to(torch.int64).sum().item()),
             'distinct_decisions': {k: int(torch.unique(events[:, c]).numel())

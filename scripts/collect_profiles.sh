@@ -11,6 +11,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# one stream: a kernel's duration in the trace is then that of a kernel that owns the chip (the product's default runs
+# timing_end on a second stream under timing_start)
+export AMT_TIMING_STREAMS=1
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- \
