@@ -77,19 +77,32 @@ __global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
         // ---- inverse, first half: thread (q = c16, k1 = j24) gathers W_q[k1 + 24 k2], transforms over k2 -> n2
         const int k1 = j24;
         const float *yb = a.Yf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
+        // f = k1 + 24 k2 <= 288 for k2 <= 11 (pair f, side 0) and > 288 for k2 >= 13 (pair 576 - f, side 1); k2 = 12: f = 288
+        // for k1 = 0 (side 0), else side 1.  One per-lane offset each way, the k2 steps are uniform: they go into the scalar
+        // base (per element the lane computed fp x stride as a 64-bit multiply-add, two selects and a compare)
+        const unsigned int vlo = (unsigned)((k1 * a.sf + 2 * c16) * 4);
+        const unsigned int vhi = (unsigned)(((FC_NF - k1) * a.sf + 32 + 2 * c16) * 4);
+        const int kstep = 24 * a.sf;                        // floats
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
-            const int f = k1 + 24 * k2;
-            const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            x[k2] = fc_at<float2>(yb, (unsigned)((fp * a.sf + side * 32 + 2 * c16) * 4));
+            if (k2 < 12) x[k2] = fc_at<float2>(yb + k2 * kstep, vlo);
+            else if (k2 > 12) x[k2] = fc_at<float2>(yb - k2 * kstep, vhi);      // (the lane offset stays non-negative: vhi >= 553 strides)
+            else x[k2] = fc_at<float2>(yb, k1 == 0 ? vlo + (unsigned)(12 * kstep * 4) : vhi - (unsigned)(12 * kstep * 4));   // (both offsets >= 0)
         }
         fc_fft24<true>(x);
         __syncthreads();                                    // the twiddle table is in place
+        // the twiddles in batches of eight reads in flight (read one by one, each product waited out its own LDS round trip)
 #pragma unroll
-        for (int n2 = 0; n2 < 24; ++n2) {
-            const float2 w = tw[n2 * k1];
-            const float2 v = cmul(x[n2], make_float2(w.x, -w.y));
-            *reinterpret_cast<float2 *>(buf + c16 * FC_PS + (n2 * 24 + k1) * 2) = v;
+        for (int g0 = 0; g0 < 24; g0 += 8) {
+            float2 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = tw[(g0 + i) * k1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float2 v = fc_cmulc(x[g0 + i], w[i]);
+                *reinterpret_cast<float2 *>(buf + c16 * FC_PS + ((g0 + i) * 24 + k1) * 2) = v;
+            }
         }
         __syncthreads();
         // ---- second half: thread (q, n2 = j24) transforms over k1 -> n1: y[24 n1 + n2]
@@ -100,13 +113,15 @@ __global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
         // ---- epilogue on the registers
         const float inv_n = 1.0f / (float)FC_NF;
         const int c0 = 2 * c16;
-        const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+        // sigmoid(x / N * s1 + t1) = 1 / (1 + 2^(x k1 + k0))
+        const float k1a = -a.s1[c0] * (inv_n * FC_LOG2E), k1b = -a.s1[c0 + 1] * (inv_n * FC_LOG2E);
+        const float k0a = -a.t1[c0] * FC_LOG2E, k0b = -a.t1[c0 + 1] * FC_LOG2E;
         if constexpr (EPI == 1) {
 #pragma unroll
             for (int n1 = 0; n1 < 24; ++n1) {
-                float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
-                v.x = fc_sigmoid(v.x * s1a + t1a);
-                v.y = fc_sigmoid(v.y * s1b + t1b);
+                float2 v;
+                v.x = fc_sigmoid_affine(x[n1].x, k1a, k0a);
+                v.y = fc_sigmoid_affine(x[n1].y, k1b, k0b);
                 if (24 * n1 + n2 >= a.W) v = make_float2(0.f, 0.f);
                 x[n1] = v;
             }
@@ -152,9 +167,9 @@ __global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int n1 = batch * NB + i, w = 24 * n1 + n2e;
-                    float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
-                    v.x = fc_sigmoid(v.x * s1a + t1a);
-                    v.y = fc_sigmoid(v.y * s1b + t1b);
+                    float2 v;
+                    v.x = fc_sigmoid_affine(x[n1].x, k1a, k0a);
+                    v.y = fc_sigmoid_affine(x[n1].y, k1b, k0b);
                     if constexpr (EPI == 2) {
                         v.x = (v.x + scv[batch & 1][i].x) * s2a + t2a;
                         v.y = (v.y + scv[batch & 1][i].y) * s2b + t2b;
@@ -201,9 +216,16 @@ __global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
         asm volatile("" : "+v"(n2), "+v"(cq));
         fc_fft24<false>(x);
 #pragma unroll
-        for (int k1 = 0; k1 < 24; ++k1) {
-            const float2 v = cmul(x[k1], tw[n2 * k1]);
-            *reinterpret_cast<float2 *>(buf + cq * FC_PS + (k1 * 24 + n2) * 2) = v;
+        for (int g0 = 0; g0 < 24; g0 += 8) {
+            float2 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = tw[n2 * (g0 + i)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float2 v = cmul(x[g0 + i], w[i]);
+                *reinterpret_cast<float2 *>(buf + cq * FC_PS + ((g0 + i) * 24 + n2) * 2) = v;
+            }
         }
         __syncthreads();
         int k1 = j24, cp = c16;
@@ -215,14 +237,20 @@ __global__ __launch_bounds__(FC_THREADS, 4) void fc_row_kernel(FcRowArgs a) {
         fc_fft24<false>(x);
         float fmax_ = 0.f;
         float *xb = a.Xf + (size_t)b * FC_NP * a.H * 64 + (size_t)h * a.sh;
+        // (addresses as in the inverse's loads: side 0 for k2 <= 11, side 1 for k2 >= 13, k2 = 12 by k1; the self-paired
+        // bins f = 0 and f = 288 -- k1 = 0 only -- fill both sides)
+        const unsigned int vlo = (unsigned)((k1 * a.sf + 2 * cp) * 4);
+        const unsigned int vhi = (unsigned)(((FC_NF - k1) * a.sf + 32 + 2 * cp) * 4);
+        const int kstep = 24 * a.sf;
 #pragma unroll
         for (int k2 = 0; k2 < 24; ++k2) {
-            const int f = k1 + 24 * k2;
-            const int fp = f <= FC_NF / 2 ? f : FC_NF - f, side = f <= FC_NF / 2 ? 0 : 1;
-            const unsigned int off = (unsigned)((fp * a.sf + 2 * cp) * 4);
-            fc_at<float2>(xb, off + side * 128) = x[k2];
-            if (f == 0 || f == FC_NF / 2) fc_at<float2>(xb, off + 128) = x[k2];          // self-paired bins fill both sides
-            fmax_ = fmaxf(fmax_, fmaxf(fabsf(x[k2].x), fabsf(x[k2].y)));
+            if (k2 < 12) fc_at<float2>(xb + k2 * kstep, vlo) = x[k2];
+            else if (k2 > 12) fc_at<float2>(xb - k2 * kstep, vhi) = x[k2];
+            else fc_at<float2>(xb, k1 == 0 ? vlo + (unsigned)(12 * kstep * 4) : vhi - (unsigned)(12 * kstep * 4)) = x[k2];
+            if (k2 == 0 || k2 == 12) {
+                if (k1 == 0) fc_at<float2>(xb + k2 * kstep, vlo + 128) = x[k2];
+            }
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(fmax_) : "v"(x[k2].x), "v"(x[k2].y));
         }
         fmax_ = wave_max(fmax_);
         if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(a.amaxf) + b, __float_as_int(fmax_));

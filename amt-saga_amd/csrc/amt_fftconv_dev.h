@@ -52,6 +52,15 @@ __device__ __forceinline__ void fc_fft24(float2 (&x)[24]) {
 // 1 / (1 + e^-v): v_rcp_f32 + one Newton step instead of the IEEE division sequence (ten instructions, 48 times per
 // thread and row: a sixth of the row kernel's vector instructions).  The step leaves the quotient within an ulp of the
 // correctly rounded one; the argument is clamped so that 1 + e^-v stays finite (the step would turn 0 x inf into NaN).
+// The epilogue's form: sigmoid(x / N * s1 + t1) = 1 / (1 + 2^(x k1 + k0)) with k1 = -s1 log2(e) / N and k0 = -t1 log2(e)
+// formed once per thread and channel: one fma, a clamp, v_exp_f32, an add, v_rcp_f32 and the Newton step -- seven instructions
+// per value where the unfolded form (two scalings, the BN multiply and add, the clamp, exp's own multiply) took ten.
+__device__ __forceinline__ float fc_sigmoid_affine(float x, float k1, float k0) {
+    const float d = 1.0f + __builtin_amdgcn_exp2f(fminf(fmaf(x, k1, k0), 125.0f));
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+#define FC_LOG2E 1.4426950408889634f
 __device__ __forceinline__ float fc_sigmoid(float v) {
     const float d = 1.0f + __expf(-fmaxf(v, -87.0f));
     const float r = __builtin_amdgcn_rcpf(d);
@@ -71,5 +80,12 @@ __device__ __forceinline__ int fc_scale_exp(float amax) {
     if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &e);
     else return 0;
     return min(max(13 - e, -90), 90);
+}
+
+
+// a * conj(b)
+__device__ __forceinline__ float2 fc_cmulc(float2 a, float2 b) {
+    const amt_v2 t = amt_v2{a.y, a.y} * amt_v2{b.y, b.x};
+    return f2(amt_v2{a.x, a.x} * amt_v2{b.x, -b.y} + t);
 }
 

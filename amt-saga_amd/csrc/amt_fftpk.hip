@@ -130,15 +130,17 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_row_kernel(PkRowArgs a) {
         // ---- epilogue on the registers: register n1 holds image row n1 / 2, column 48 (n1 & 1) + n2 (valid: n1 < 20 and
         // column < 64); everything else of the sequence is the zero padding the next transform needs
         const float inv_n = 1.0f / (float)PK_NF;
-        const float s1a = a.s1[c0], s1b = a.s1[c0 + 1], t1a = a.t1[c0], t1b = a.t1[c0 + 1];
+        // sigmoid(x / N * s1 + t1) = 1 / (1 + 2^(x k1 + k0))
+        const float k1a = -a.s1[c0] * (inv_n * FC_LOG2E), k1b = -a.s1[c0 + 1] * (inv_n * FC_LOG2E);
+        const float k0a = -a.t1[c0] * FC_LOG2E, k0b = -a.t1[c0 + 1] * FC_LOG2E;
         const bool odd_ok = n2 < PK_W - 48;
         if constexpr (EPI == 1) {
 #pragma unroll
             for (int n1 = 0; n1 < 24; ++n1) {
                 if (n1 >= 2 * PK_H) { x[n1] = make_float2(0.f, 0.f); continue; }
-                float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
-                v.x = fc_sigmoid(v.x * s1a + t1a);
-                v.y = fc_sigmoid(v.y * s1b + t1b);
+                float2 v;
+                v.x = fc_sigmoid_affine(x[n1].x, k1a, k0a);
+                v.y = fc_sigmoid_affine(x[n1].y, k1b, k0b);
                 if ((n1 & 1) && !odd_ok) v = make_float2(0.f, 0.f);
                 x[n1] = v;
             }
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_row_kernel(PkRowArgs a) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int n1 = batch * NB + i;
-                    float2 v = make_float2(x[n1].x * inv_n, x[n1].y * inv_n);
-                    v.x = fc_sigmoid(v.x * s1a + t1a);
-                    v.y = fc_sigmoid(v.y * s1b + t1b);
+                    float2 v;
+                    v.x = fc_sigmoid_affine(x[n1].x, k1a, k0a);
+                    v.y = fc_sigmoid_affine(x[n1].y, k1b, k0b);
                     if constexpr (RES) {
                         v.x = (v.x + scv[batch & 1][i].x) * s2a + t2a;
                         v.y = (v.y + scv[batch & 1][i].y) * s2b + t2b;

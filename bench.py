@@ -25,8 +25,8 @@ Prints ONE JSON line on rank 0 with the driver contract plus
   value_f32_mfma          the same step with the strict-f32 convolutions (--conv-mode 0), same run
   value_one_stream_profiled     the measurement pass behind the roofline objects: the same steps with both timing networks
                           on ONE stream (a kernel's duration is then that of a kernel that owns the chip) and HIP events
-                          around every conv layer / STFT / subtract launch, outside the timed region.  `value` itself runs
-                          timing_end on a second stream under timing_start (TranscriptionLoop.timing_streams = 2, the default)
+                          around every conv layer / STFT / subtract launch, outside the timed region (the product's default
+                          is one stream too; AMT_TIMING_STREAMS=2 is an opt-in that is not safe at this size: DESIGN 10)
   value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
                           (SURVEY 8d defines the metric including that copy; never `value`)
   value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
@@ -259,7 +259,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # ---- the timed region: the product as it runs (timing_end on a second stream under timing_start) -----------------
+    # ---- the timed region: the product as it runs -----------------
     dt, (events, last) = timed_steps(args.steps, step)
     value = B * world * args.steps / dt
     # ---- per-kernel measurement pass, OUTSIDE the timed region: the same steps on ONE stream, so that a kernel's duration
