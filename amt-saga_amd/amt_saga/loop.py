@@ -68,10 +68,12 @@ class TranscriptionLoop:
             from . import sf2 as _sf2
             soundfont = _sf2.SoundFont(soundfont)
         self.soundfont = soundfont
-        # AMT_TIMING_STREAMS=2: timing_end on a second HIP stream under timing_start (+2.4 ... +4.5 % on a C3 step).  NOT the
-        # default and not safe at the metric size: with the FFT-domain layers two timing networks that really overlap in time
-        # return wrong floats for some windows (12 of 12 trials at 516 frames, never when serialised; DESIGN 10, open issue);
-        # the 86-frame windows of the small tests are too short to overlap, which is why round 3 did not see it
+        # AMT_TIMING_STREAMS=2: timing_end on a second HIP stream under timing_start (-1 ... +3 % on a C3 step, run to run).
+        # Opt-in.  Until round 4's fix two timing networks that really overlapped in time returned wrong floats at the
+        # metric size: packed-FP32 vector instructions (v_pk_mul / add / fma_f32) of the transform kernels compute wrong
+        # values in lanes 48-63 while a wave of ANOTHER dispatch issues v_mfma_f32_16x16x32_f16 on the same SIMD
+        # (DESIGN 10.1); the network kernels are built without those instructions now (build.py NO_PK) and the full-size
+        # fixtures pass on two streams (tests/test_gpu_fullsize_fixtures.py)
         self.timing_streams = int(os.environ.get('AMT_TIMING_STREAMS', '1'))
         # the subtraction on the guess's frames only (amt_subtract_span): the residual is a magnitude spectrogram (>= 0) and
         # the timing features' compress_bands pass leaves the per-frame maxima on the way; AMT_SUBTRACT_SPAN=0: whole windows

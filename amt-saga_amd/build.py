@@ -26,7 +26,15 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math'
 # STFT / iSTFT and the CQT accumulations are tolerance-checked floating point (1e-4 against the oracle): fused multiply-adds
 # there cost nothing in parity and save ~a quarter of the vector instructions.  Everything that is
 # compared bit for bit (subtract, the conv epilogues, the f32 MFMA chains) keeps contraction off.
-FILE_FLAGS = {'amt_stft.hip': ['-ffp-contract=fast'], 'amt_cqt.hip': ['-ffp-contract=fast']}
+# No packed-FP32 vector instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in any kernel of the networks: measured
+# on MI355X (round 4, scripts/probes/two_stream_repro.py), they return wrong values in lanes 48-63 of a wave
+# while a wave of ANOTHER dispatch issues back-to-back v_mfma_f32_16x16x32_f16 on the same SIMD -- i.e. whenever a
+# transform kernel of one timing network shares CUs with the split-fp16 convolutions of the other (two streams).  With
+# the instructions gone the same schedule is bit-identical to the serial one; the step time does not change (the
+# transforms are not bound by vector issue).
+NO_PK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+FILE_FLAGS = {'amt_stft.hip': ['-ffp-contract=fast'], 'amt_cqt.hip': ['-ffp-contract=fast'],
+              'amt_fftconv.hip': NO_PK, 'amt_fftpk.hip': NO_PK, 'amt_rdcnn.hip': NO_PK}
 
 
 def _newer(a, b):
@@ -37,7 +45,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
-        [os.path.join(ROOT, 'include', 'amt_saga.h')]
+        [os.path.join(ROOT, 'include', 'amt_saga.h'), os.path.abspath(__file__)]      # (the flags live in this file)
     objs = []
     procs = []
     for s in srcs:

@@ -26,7 +26,9 @@ Prints ONE JSON line on rank 0 with the driver contract plus
   value_one_stream_profiled     the measurement pass behind the roofline objects: the same steps with both timing networks
                           on ONE stream (a kernel's duration is then that of a kernel that owns the chip) and HIP events
                           around every conv layer / STFT / subtract launch, outside the timed region (the product's default
-                          is one stream too; AMT_TIMING_STREAMS=2 is an opt-in that is not safe at this size: DESIGN 10)
+                          is one stream too)
+  value_two_timing_streams  the same step with timing_end on a second HIP stream under timing_start (TranscriptionLoop.
+                          timing_streams = 2, opt-in; parity-tested at the metric size since round 4's fix: DESIGN 10.1)
   value_h2d_inclusive     the same step with the batch's audio copied host -> HBM inside the timed region
                           (SURVEY 8d defines the metric including that copy; never `value`)
   value_h2d_overlapped    the same with that copy on a second stream, overlapped with the previous batch's compute
@@ -488,6 +490,15 @@ def main():
 
     # ---- extra legs, same run ----------------------------------------------------------------
     extras = {}
+    if not args.no_extras and 'timing' in loop.heads and loop.timing_streams == 1:
+        # (0) timing_end on a second stream under timing_start (opt-in mode of the product)
+        loop.timing_streams = 2
+        step()
+        k2s = max(1, min(args.steps, 5))
+        dt2s, (ev2s, _) = timed_steps(k2s, step)
+        loop.timing_streams = 1
+        extras['value_two_timing_streams'] = round(B * world * k2s / dt2s, 2)
+        extras['two_timing_streams_same_events'] = bool(torch.equal(ev2s, events))
     if not args.no_extras:
         # (1) strict-f32 convolutions
         if conv_mode != 0 and loop.nets:

@@ -113,3 +113,66 @@ def test_fftpk_layer_vs_numpy(B, residual, chain):
     print('fftpk B=%d residual=%s chain=%d: e_gpu %.3g  e_cpu(f32 direct) %.3g' % (B, residual, chain, e_gpu, e_cpu))
     assert e_gpu < 1e-5, e_gpu
     assert e_gpu <= 2.5 * e_cpu + 2.4e-7, (e_gpu, e_cpu)
+
+
+@pytest.mark.parametrize('form', ['row', 'packed'])
+def test_fft_layer_beside_split_fp16_network_on_a_second_stream(form):
+    """Regression for round 4's two-stream hazard (scripts/probes/two_stream_repro.py): an FFT-domain layer
+    running while the split-fp16 convolutions (v_mfma_f32_16x16x32_f16) of a timing network run on a second HIP stream must
+    return exactly what it returns alone.  With packed-FP32 vector instructions in the transform kernels it did not (8 of
+    8 trials): those instructions return wrong values in lanes 48-63 while another dispatch's MFMA wave shares the SIMD;
+    the kernels of the networks are built without them (build.py NO_PK)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import fixture_waves as fw
+    from amt_saga import _lib
+    from amt_saga.device import stream_ptr
+    from amt_saga.loop import TranscriptionLoop
+    lib = _lib.load()
+    B = 16
+    rng = np.random.default_rng(3)
+    cn = 32 if form == 'row' else 64
+    k = (rng.standard_normal((4, 16, cn, cn)) * 0.05).astype(np.float32)
+    s, t = np.ones(cn, np.float32), np.zeros(cn, np.float32)
+    h = C.c_void_p()
+    fp = lambda x: x.ctypes.data_as(C.c_void_p)
+    create, destroy = (lib.amt_fftconv_create, lib.amt_fftconv_destroy) if form == 'row' else (lib.amt_fftpk_create, lib.amt_fftpk_destroy)
+    _lib.check(create(C.byref(h), fp(k), fp(s), fp(t), fp(s), fp(t)))
+    try:
+        a = torch.rand((B, 20, 516, 32) if form == 'row' else (B, 10, 64, 64), device='cuda')
+        o = torch.empty_like(a)
+        need = lib.amt_fftconv_workspace_bytes(B, 20) if form == 'row' else lib.amt_fftpk_workspace_bytes(B)
+        ws = torch.empty((need + 3) // 4, device='cuda')
+
+        def run():
+            if form == 'row':
+                _lib.check(lib.amt_fftconv_run(h, a.data_ptr(), a.data_ptr(), B, 20, 516, o.data_ptr(), ws.data_ptr(), need, 1, stream_ptr()))
+            else:
+                _lib.check(lib.amt_fftpk_run(h, a.data_ptr(), a.data_ptr(), B, o.data_ptr(), ws.data_ptr(), need, 0, 1, stream_ptr()))
+        c, p = fw.CASES['c3'], fw.params_for('c3')
+        wave = torch.from_numpy(fw.pcm_to_wave(fw.render_pcm('c3', fw.note_lists('c3', B)))).cuda()
+        lp = TranscriptionLoop(p, heads=('timing',), iters=1, groups=c['groups'], subtract=False).setup_device()
+        batch = lp.prepare(wave)
+        ct = batch.compress_bands(p.timing_bands, lp.refs['ref_mag'], p.timing_frames)
+        net = lp.nets['timing_end']
+        net.set_mode(2)                                        # split-fp16 direct convolutions only
+        want_net = net.classify(ct).clone()
+        run()
+        torch.cuda.synchronize()
+        want = o.clone()
+        side, cur = torch.cuda.Stream(), torch.cuda.current_stream()
+        for trial in range(6):
+            o.zero_()
+            torch.cuda.synchronize()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                y = net.classify(ct)
+            run()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(o, want), (form, trial, float((o - want).abs().max()))
+            assert torch.equal(y, want_net), (form, trial)
+    finally:
+        destroy(h)

@@ -35,8 +35,8 @@ def _waves(case, fx):
     return fw.pcm_to_wave(pcm)
 
 
-@pytest.mark.parametrize('case', ['c3', 'c5'])
-def test_fullsize_loop_vs_oracle_fixture(case, fx):
+@pytest.mark.parametrize('case,streams', [('c3', 1), ('c5', 1), ('c3', 2), ('c5', 2)])
+def test_fullsize_loop_vs_oracle_fixture(case, streams, fx):
     import torch
     from amt_saga.loop import TranscriptionLoop
     from oracle import audio as oa
@@ -46,6 +46,7 @@ def test_fullsize_loop_vs_oracle_fixture(case, fx):
     wave_h = _waves(case, fx)
     B = wave_h.shape[0]
     lp = TranscriptionLoop(p, heads=c['heads'], iters=c['iters'], groups=c['groups']).setup_device()
+    lp.timing_streams = streams                               # 2: timing_end on a second stream under timing_start (opt-in)
     lp.trace = []
     events, b = lp.run(torch.from_numpy(wave_h).cuda())
     torch.cuda.synchronize()
@@ -83,8 +84,9 @@ def test_fullsize_loop_vs_oracle_fixture(case, fx):
         want = fx[case + '_resid_q'][i].astype(np.float64) * s
         m = mag[i][:, :F].T
         assert np.abs(m - want).max() <= (1e-4 + 1.0 / 65535) * want.max(), ('residual', case, i)
-    print('%s: %d windows of %d frames x %d iterations against the oracle fixture: events bit-exact, worst float '
-          'distances %s' % (case, B, p.timing_frames, c['iters'], {k: '%.2g' % v for k, v in worst.items()}))
+    print('%s (%d timing stream%s): %d windows of %d frames x %d iterations against the oracle fixture: events bit-exact, '
+          'worst float distances %s' % (case, streams, 's' * (streams > 1), B, p.timing_frames, c['iters'],
+                                        {k: '%.2g' % v for k, v in worst.items()}))
 
 
 def test_fullsize_normaliser_grids_both_forms(fx):
