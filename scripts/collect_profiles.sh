@@ -11,8 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# one stream: a kernel's duration in the trace is then that of a kernel that owns the chip (the product's default runs
-# timing_end on a second stream under timing_start)
+# one stream (the product's default): a kernel's duration in the trace is that of a kernel that owns the chip
 export AMT_TIMING_STREAMS=1
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
