@@ -10,6 +10,8 @@ import bisect
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -35,8 +37,14 @@ def _plan(n_fft, hop, center):
     return _PLANS[key]
 
 
+# Row pitch of the spectrograms in floats.  AMT_LDF_ALIGN=32 (128-byte rows) is a measured experiment, not a supported
+# mode: the STFT's write traffic drops from 2.39 to 2.25 MB per window (3.55 -> 3.41 in total, PMC) at unchanged speed, the
+# other kernels carry 2.7 % more bytes, and the host-side window-management helpers (gather_frames) assume the default
+_LDF_ALIGN = int(os.environ.get('AMT_LDF_ALIGN', '4'))
+
+
 def ldf_of(n_fft):
-    return ((n_fft // 2 + 1) + 3) & ~3
+    return ((n_fft // 2 + 1) + _LDF_ALIGN - 1) // _LDF_ALIGN * _LDF_ALIGN
 
 
 def fft_frequencies(sr, n_fft):

@@ -13,8 +13,10 @@
 //    twiddles; the Hann window is derived from the same table
 //    (w[n] = 0.5 - 0.5*Re W[n]).
 //  * samples are read straight from global memory, consecutive threads ->
-//    consecutive samples (the 75 % frame overlap is served by L2; HBM sees each
-//    sample once); the librosa reflect padding is an index map, never a copy.
+//    consecutive samples; the librosa reflect padding is an index map, never a
+//    copy.  The 75 % frame overlap: the 2048 / hop 512 magnitude-only form keeps
+//    a thread's ten samples of a frame pair in registers and loads only the four
+//    new ones for the next pair (round 4); every other form re-reads through L2.
 //  * spectra are written frame-major [t][f]: consecutive threads -> consecutive
 //    bins, so every store instruction covers whole 128-B lines.
 //  * |X| max is reduced wave -> block -> one atomicMax per block (non-negative
@@ -28,17 +30,18 @@ struct amt_stft_plan {
 
 thread_local char amt_hip_err_buf[256] = {0};
 
-// (the magnitude-only 2048-point form fits 64 registers without spills: eight workgroups per CU, which is also what its
-// 20 KB of LDS allow)
+// (the magnitude-only 2048-point form: 80 registers with the ten carried samples -- six workgroups per CU, four spilled
+// registers; five workgroups without spills measured 1.5 % slower, eight with thirteen spills did not fit the carry;
+// round 3's form without the carry fitted 64 registers and eight workgroups and was 1.5-4 % slower at 9 % more HBM reads)
 // Measured negative: the inter-stage twiddles are per-thread constants too (butterfly index = thread index), but
 // holding all of them costs 40 registers -> 138, three waves per SIMD: 1.43 ms against 1.20; capped at 128 / 96 registers
 // the compiler spills 8 / 37 of them.
 template <int N, bool WITH_PHASE>
-__global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 8 : 1) void stft_mag_kernel(
+__global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 6 : 1) void stft_mag_kernel(
     const float *__restrict__ wave, int L, size_t wave_stride,
     float *__restrict__ mag, float2 *__restrict__ phase, float *__restrict__ ref_max,
     int T, int ldf, size_t spec_stride, const float2 *__restrict__ tw_global,
-    int hop, int center, int pairs_per_block) {
+    int hop, int center, int pairs_per_block, int reuse_ok) {
     // the first pass of fft_block reads elements tid + r * (N / 8) (radix 8, one butterfly per thread for N = 2048):
     // the same eight positions of every frame pair, so their Hann weights are formed once per workgroup, straight from
     // the global table -- and the LDS copy then only needs the entries the inter-stage twiddles touch: k * N / (NS R)
@@ -64,6 +67,17 @@ __global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 8 : 1
     float2 *ph = WITH_PHASE ? phase + (size_t)b * spec_stride : nullptr;
     const int pad = center ? N / 2 : 0;
     float lmax = 0.f;
+    // Interior pairs of the hoisted form (N = 8 x 256 threads) with hop = N / 4: thread `tid` needs samples s0 + tid + 256 j,
+    // j = 0 .. 7 for the first frame and j = 2 .. 9 for the second, and the next pair (s0 + 2 hops = s0 + 4 x 256) needs
+    // j = 4 .. 13 of the same sequence: six of its ten samples are already in this thread's registers.  Kept there, a pair
+    // costs 4 loads per thread instead of 16 and the 75 % frame overlap no longer goes to L2 at all (round 3: 1.54 MB read
+    // per window against 1.055 of audio, the re-reads missing L2 under the 2 GB stream of magnitudes).
+    constexpr bool REUSE = HOIST && !WITH_PHASE;
+    const bool reuse = REUSE && reuse_ok && hop == 2 * AMT_FFT_THREADS;
+    float sw[10];
+    bool have = false;                                   // (uniform) sw holds the previous pair's samples
+#pragma unroll
+    for (int j = 0; j < 10; ++j) sw[j] = 0.f;
     for (int p = 0; p < pairs_per_block; ++p) {
         const int t0 = 2 * (blockIdx.x * pairs_per_block + p);
         if (t0 >= T) break;                       // uniform across the block
@@ -87,8 +101,27 @@ __global__ __launch_bounds__(AMT_FFT_THREADS, (N == 2048 && !WITH_PHASE) ? 8 : 1
             const float w = HOIST ? wn[(n - tid) / NB1] : 0.25f - 0.25f * tw[n].x;
             return make_float2(w0[n] * w, w0[n + hop] * w);
         };
-        if (interior) fft_block<N, false>(buf, tw, load_in);
-        else fft_block<N, false>(buf, tw, load_edge);
+        if (REUSE && reuse && interior) {
+            if (have) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) sw[j] = sw[j + 4];
+#pragma unroll
+                for (int j = 6; j < 10; ++j) sw[j] = w0[tid + AMT_FFT_THREADS * j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) sw[j] = w0[tid + AMT_FFT_THREADS * j];
+            }
+            have = true;
+            auto load_regs = [&](int n) -> float2 {
+                const int r = (n - tid) / NB1;            // (compile-time after unrolling, as for wn[])
+                return make_float2(sw[r] * wn[r], sw[r + 2] * wn[r]);
+            };
+            fft_block<N, false>(buf, tw, load_regs);
+        } else {
+            have = false;
+            if (interior) fft_block<N, false>(buf, tw, load_in);
+            else fft_block<N, false>(buf, tw, load_edge);
+        }
 
         // The window above is Hann / 2 (a power-of-two factor: exact), which is the 1/2 of the separation
         //   X_t[k] = (Z[k] + conj Z[N-k]) / 2,  X_{t+1}[k] = (Z[k] - conj Z[N-k]) / (2i).
@@ -397,14 +430,16 @@ static int launch_stft(const amt_stft_plan *plan, const float *wave, int B, int 
     // at least ~8 rounds of the 2048 workgroups the chip holds (8 per CU): fewer, longer workgroups leave a tail
     while (ppb > 1 && (size_t)((pairs + ppb - 1) / ppb) * B < 16384) ppb >>= 1;
     dim3 grid((pairs + ppb - 1) / ppb, B);
+    static int reuse_ok = -1;                            // AMT_STFT_REUSE=0: every pair loads its 16 samples per thread (diagnostic)
+    if (reuse_ok < 0) { const char *e = getenv("AMT_STFT_REUSE"); reuse_ok = !(e && atoi(e) == 0); }
     if (phase)
         stft_mag_kernel<N, true><<<grid, AMT_FFT_THREADS, 0, st>>>(
             wave, L, wave_stride, mag, reinterpret_cast<float2 *>(phase), ref_max, T, ldf,
-            spec_stride, plan->tw_dev, plan->hop, plan->center, ppb);
+            spec_stride, plan->tw_dev, plan->hop, plan->center, ppb, reuse_ok);
     else
         stft_mag_kernel<N, false><<<grid, AMT_FFT_THREADS, 0, st>>>(
             wave, L, wave_stride, mag, nullptr, ref_max, T, ldf, spec_stride, plan->tw_dev,
-            plan->hop, plan->center, ppb);
+            plan->hop, plan->center, ppb, reuse_ok);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
