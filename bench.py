@@ -280,6 +280,10 @@ def main():
     def timed(fn, tag):
         def w(self, *a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # (this pass only) keep the stream busy for ~1 ms before the first event: the STFT opens a step on an idle
+            # GPU, and without this the host's enqueue latency (three allocations and a ctypes call, ~0.15 ms) sits
+            # between the two events and is priced as kernel time (round 4: 1.105 ms by the events, 0.937 by rocprofv3)
+            torch.cuda._sleep(2000000)
             e0.record()
             r = fn(self, *a, **k)
             e1.record()
